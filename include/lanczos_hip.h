@@ -1,0 +1,262 @@
+/*
+ * lanczos_hip.h -- C ABI of the MI355X (gfx950) Lanczos engine.
+ *
+ * This is the whole boundary between a C host program and the HIP engine:
+ * plain pointers and sizes, no C++ types, no exceptions.  A host that today
+ * calls lanczos_cuda_crs() (reference src/lanczos_cuda.h:139-141) links
+ * liblanczos_hip.so and calls lanczos_hip_crs() with the same arguments.
+ *
+ * Return convention (all int-returning functions): 0 (== EXIT_SUCCESS) on
+ * success, non-zero on failure.  On failure a one-line message has been
+ * printed to stdout, the way the reference's CHECK_*_GOTO macros do
+ * (src/lanczos_cuda.h:76-124), and lanczos_hip_last_error() returns it.
+ */
+#ifndef LANCZOS_HIP_H
+#define LANCZOS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Host matrix types.  Field-for-field the reference's Coo / Mat_Coo
+ * (src/coo.h:3-13) and Mat_Crs (src/crs.h:4-21), so a Mat_Crs built by the
+ * reference's convert_from_coo() can be handed over unchanged.  A translation
+ * unit that already included the reference's coo.h / crs.h defines
+ * LANCZOS_HIP_HAVE_REFERENCE_TYPES before including this header.
+ */
+#ifndef LANCZOS_HIP_HAVE_REFERENCE_TYPES
+typedef struct coo {
+    int index_row;
+    int index_column;
+    double value;
+} Coo;
+
+typedef struct mat_coo {
+    Coo *data;
+    size_t length;
+    size_t dimension;
+} Mat_Coo;
+
+typedef struct crs {
+    double *values;
+    int64_t *column_index;
+    int64_t *row_head_indexes; /* length dimension + 1, last entry == length */
+    size_t length;
+    size_t dimension;
+} Mat_Crs;
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Drop-in solver entry                                                      */
+/* ------------------------------------------------------------------------ */
+
+/*
+ * Replaces lanczos_cuda_crs (src/lanczos_cuda.h:139-141, body
+ * src/lanczos_cuda.c:281-788); same argument meaning:
+ *   mat           CRS matrix on the host, owned by the caller, not modified
+ *   eigenvalues   caller buffer of >= nth_eig doubles; zero-filled on entry
+ *                 (src/lanczos_cuda.c:359), on return the lowest nth_eig Ritz
+ *                 values of the last tridiagonal matrix, ascending, entries
+ *                 beyond its dimension zero (src/util.c:269-271)
+ *   eigenvectors  accepted and ignored, as in both reference solvers
+ *                 (src/lanczos.c:20, src/lanczos_cuda.c:284)
+ *   max_iter      basis size; the loop runs max_iter - 1 iterations
+ *                 (src/lanczos.c:104)
+ *   threshold     convergence threshold of src/lanczos.c:123, 185
+ * Termination, iteration-line printing and the reorthogonalisation range
+ * follow the CPU solver src/lanczos.c:104-191 (all l < k), which is the parity
+ * target; stdout carries the same lines ("%d\t%.7f\t...", "converged ...",
+ * "%.7f beta converged", "Reached max iterations (%d)"), stderr the
+ * "[TOTAL] name=... sec=..." lines of src/lanczos_cuda.c:782-786.
+ * Returns EXIT_SUCCESS on max-iter and on either convergence exit,
+ * EXIT_FAILURE on bad arguments or a HIP error (src/lanczos_cuda.c:316-327).
+ *
+ * Environment knobs (the argv contract of src/main.c:25-42 is unchanged):
+ *   LANCZOS_HIP_REORTH  full | full2 | mgs | cuda_compat | none   (default full)
+ *   LANCZOS_HIP_SEED    start-vector seed (default 123456789, the constant of
+ *                       src/lanczos_cuda.c:395)
+ *   LANCZOS_HIP_DEVICE  HIP device ordinal (default: current device)
+ *   LANCZOS_HIP_QUIET   1 suppresses the per-iteration stdout lines
+ */
+int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
+                    int nth_eig, int max_iter, double threshold);
+
+/* ------------------------------------------------------------------------ */
+/* Engine handle API (what lanczos_hip_crs is built from; used by tests and  */
+/* benchmarks, and by multi-GPU hosts that interleave collectives)           */
+/* ------------------------------------------------------------------------ */
+
+typedef struct lanczos_hip_engine lanczos_hip_engine;
+
+/* Reorthogonalisation range/order of one iteration k. */
+enum {
+    LANCZOS_HIP_REORTH_FULL = 0,        /* all l < k (src/lanczos.c:156), one blocked
+                                           classical Gram-Schmidt pass after the
+                                           three-term recurrence */
+    LANCZOS_HIP_REORTH_CUDA_COMPAT = 1, /* l < k-2 (src/lanczos_cuda.c:679-687) */
+    LANCZOS_HIP_REORTH_NONE = 2,        /* three-term recurrence only; keeps 3 vectors */
+    LANCZOS_HIP_REORTH_MGS = 3,         /* all l < k, one basis vector at a time in
+                                           ascending l: the exact order of
+                                           src/lanczos.c:156-167 */
+    LANCZOS_HIP_REORTH_FULL2 = 4        /* all l < k, two blocked passes */
+};
+
+enum {
+    LANCZOS_HIP_SPMV_AUTO = 0,
+    LANCZOS_HIP_SPMV_VECTOR = 1, /* 2^g lanes per row, g chosen from mean row length */
+    LANCZOS_HIP_SPMV_STREAM = 2  /* one wavefront per group of rows, nnz streamed through LDS */
+};
+
+/* Kernel classes for lanczos_hip_profile(). */
+enum {
+    LANCZOS_HIP_K_SPMV = 0,
+    LANCZOS_HIP_K_RECUR = 1,
+    LANCZOS_HIP_K_SCALE = 2,
+    LANCZOS_HIP_K_DOTS = 3,
+    LANCZOS_HIP_K_UPDATE = 4,
+    LANCZOS_HIP_K_SMALL = 5, /* partial-sum finalisers */
+    LANCZOS_HIP_K_COUNT = 6
+};
+
+typedef struct lanczos_hip_options {
+    size_t struct_size;  /* sizeof(lanczos_hip_options), for forward compatibility */
+    int device;          /* HIP device ordinal, -1 = the current device */
+    void *stream;        /* hipStream_t to launch on; NULL = a private non-blocking
+                            stream, as src/lanczos_cuda.c:364 */
+    int reorth;          /* LANCZOS_HIP_REORTH_* */
+    int spmv_kernel;     /* LANCZOS_HIP_SPMV_* */
+    int profile;         /* non-zero: bracket every kernel with HIP events and
+                            accumulate per-class time (lanczos_hip_profile) */
+    /*
+     * Row-partitioned (multi-GPU) use.  The engine then holds rows
+     * [row_begin, row_begin + n) of an n_global-row matrix; column_index
+     * values passed to lanczos_hip_create index an external gather buffer
+     * x_ext of n_ext doubles that the host fills (all-gather or halo exchange)
+     * before each SpMV.  Leave all of them 0 / NULL for single-GPU use.
+     */
+    int64_t n_global;
+    int64_t row_begin;
+    int64_t n_ext;
+    double *x_ext; /* device pointer, n_ext doubles, owned by the caller */
+} lanczos_hip_options;
+
+/*
+ * Upload a CRS matrix (the three arrays of Mat_Crs, src/crs.h:4-21) and
+ * allocate the Krylov basis: max_iter vectors of n doubles as
+ * src/lanczos_cuda.c:424-427 does, or 3 vectors with LANCZOS_HIP_REORTH_NONE.
+ * Column indices are narrowed to 32 bits on the device (the reference caps the
+ * dimension at INT_MAX, src/lanczos_cuda.c:319-322) and row offsets to 32 bits
+ * when nnz < 2^31.  Replaces create_cusparse_matrix (src/lanczos_cuda.c:32-260)
+ * plus the allocations of src/lanczos_cuda.c:424-427.
+ */
+int lanczos_hip_create(lanczos_hip_engine **out, int64_t n, int64_t nnz,
+                       const int64_t *row_head_indexes, const int64_t *column_index,
+                       const double *values, int max_iter, const lanczos_hip_options *opt);
+
+/* Replaces destroy_cusparse_matrix and the cleanup block src/lanczos_cuda.c:720-779. */
+void lanczos_hip_destroy(lanczos_hip_engine *e);
+
+/*
+ * Start vector.  set_start copies n host doubles into basis slot 0 and
+ * normalises them by multiplying with 1/sqrt(v.v) (src/lanczos.c:95-98,
+ * src/lanczos_cuda.c:436-442); set_start_seed draws N(0,1) entries on the host
+ * from a counter-based generator (element i depends only on seed and the
+ * global row index, so every row partition sees the same vector) -- the
+ * deterministic stand-in for src/util.c:48-56 / src/lanczos_cuda.c:394-432.
+ * Both reset the iteration counter to 0.  In row-partitioned use the norm must
+ * be global: pass it through lanczos_hip_set_start_scaled.
+ */
+int lanczos_hip_set_start(lanczos_hip_engine *e, const double *v0_host);
+int lanczos_hip_set_start_seed(lanczos_hip_engine *e, uint64_t seed);
+/* Fill out[0..n) with the seed's N(0,1) sequence for global rows
+ * [row_begin, row_begin+n) (host only, no GPU needed). */
+void lanczos_hip_gaussian_fill(uint64_t seed, int64_t row_begin, int64_t n, double *out);
+
+/*
+ * Run `steps` more iterations of src/lanczos.c:104-191 / src/lanczos_cuda.c:557-714
+ * without host round trips, then return alpha_k and beta_k of those
+ * iterations (host arrays of `steps` doubles; either may be NULL).  Blocks
+ * until the stream has drained.  At most max_iter - 1 iterations in total
+ * (3-vector mode: unlimited).
+ */
+int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out);
+
+/* Number of iterations completed since the last set_start. */
+int lanczos_hip_iterations(const lanczos_hip_engine *e);
+
+/* Test hook: y = A x with host vectors of n_ext (x) and n (y) doubles, through
+ * the same SpMV kernel the iteration uses (src/crs.c:155-178,
+ * src/lanczos_cuda.c:562-577). */
+int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host);
+
+/* Copy basis vector k (n doubles) to the host. */
+int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host);
+
+/*
+ * Per-class kernel statistics gathered when options.profile != 0:
+ * accumulated HIP-event milliseconds, launch count and algorithmic bytes
+ * (each operand read once, each result written once).
+ */
+int lanczos_hip_profile(const lanczos_hip_engine *e, int kernel_class, double *ms,
+                        int64_t *launches, double *bytes);
+void lanczos_hip_profile_reset(lanczos_hip_engine *e);
+
+/* Name of the SpMV kernel variant the engine selected ("vector8", "stream", ...). */
+const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
+
+/*
+ * Lowest m eigenvalues, ascending, of the symmetric tridiagonal matrix with
+ * diagonal alpha[0..n) and off-diagonal beta[0..n-1), by Sturm-sequence
+ * bisection on the host.  Replaces the dense MKL / cuSOLVER solve of
+ * src/util.c:118-272 and src/lanczos_cuda.c:598-640, which are handed the same
+ * tridiagonal matrix in dense form every step.  Entries eig[min(m,n)..m) are
+ * zeroed (src/util.c:269-271).
+ */
+int lanczos_hip_tridiag_eigs(const double *alpha, const double *beta, int n, int m, double *eig);
+
+/* Message of the most recent failure on the calling thread ("" if none). */
+const char *lanczos_hip_last_error(void);
+
+/* ------------------------------------------------------------------------ */
+/* Phase-level entry points for row-partitioned runs                         */
+/* ------------------------------------------------------------------------ */
+/*
+ * One iteration k, split where a multi-GPU host must reduce across ranks.
+ * Each call only enqueues kernels on the engine's stream.  `red` is a device
+ * buffer of doubles owned by the caller; a phase leaves this rank's partial
+ * sums there and the host all-reduces them in place (sum) before the next
+ * phase, which reads the reduced values.  The reference has no multi-GPU code;
+ * these have no counterpart in it beyond the loop body they split
+ * (src/lanczos.c:109-190).
+ *
+ *   lanczos_hip_phase_spmv    w = A x_ext ; red[0] = local v_k . w
+ *   lanczos_hip_phase_recur   alpha = red[0] ; w -= beta_prev v_{k-1} + alpha v_k ;
+ *                             red[0..nl) = local V_l . w for the nl basis vectors
+ *                             of the reorthogonalisation range (nl returned in *n_red;
+ *                             with nl == 0: red[0] = local w.w and *n_red = 1,
+ *                             *is_norm = 1)
+ *   lanczos_hip_phase_update  w -= sum_l red[l] V_l ; red[0] = local w.w
+ *   lanczos_hip_phase_scale   beta = sqrt(red[0]) ; v_{k+1} = w / beta ; k += 1
+ *
+ * lanczos_hip_local_vector returns the device address of basis vector k's
+ * local slab so the host can gather it into x_ext.
+ */
+int lanczos_hip_phase_spmv(lanczos_hip_engine *e, double *red);
+int lanczos_hip_phase_recur(lanczos_hip_engine *e, double *red, int *n_red, int *is_norm);
+int lanczos_hip_phase_update(lanczos_hip_engine *e, double *red);
+int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red);
+double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k);
+/* v_0 = scale * v0_host, for a caller that has reduced the norm across ranks. */
+int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, double scale);
+/* Copy alpha/beta history [0, iterations) from the device (row-partitioned
+ * runs record the reduced values as the phases consume them). */
+int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_out, int count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LANCZOS_HIP_H */

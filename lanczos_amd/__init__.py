@@ -1,0 +1,346 @@
+"""Python host-side mirror of the reference's C interface, over the C ABI.
+
+Every function here is a thin ctypes call into ``lib/liblanczos_hip.so`` (the
+HIP engine, ``include/lanczos_hip.h``) or ``lib/liblanczos_host.so`` (the host
+C API kept from the reference, ``include/lanczos_host.h``).  There is no
+Python or CPU implementation behind them: if the libraries are missing the
+import fails.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_HIP = os.path.join(_HERE, "lib", "liblanczos_hip.so")
+LIB_HOST = os.path.join(_HERE, "lib", "liblanczos_host.so")
+
+if not (os.path.exists(LIB_HIP) and os.path.exists(LIB_HOST)):
+    raise ImportError(
+        f"{LIB_HIP} / {LIB_HOST} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C lanczos_amd/csrc`); this package has no fallback path")
+
+_hip = C.CDLL(LIB_HIP, mode=C.RTLD_GLOBAL)
+_host = C.CDLL(LIB_HOST)
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int64)
+
+COO_DTYPE = np.dtype([("index_row", np.int32), ("index_column", np.int32), ("value", np.float64)], align=True)
+
+
+class Coo(C.Structure):
+    _fields_ = [("index_row", C.c_int), ("index_column", C.c_int), ("value", C.c_double)]
+
+
+class Mat_Coo(C.Structure):
+    _fields_ = [("data", C.POINTER(Coo)), ("length", C.c_size_t), ("dimension", C.c_size_t)]
+
+
+class Mat_Crs(C.Structure):
+    _fields_ = [("values", _dp), ("column_index", _ip), ("row_head_indexes", _ip),
+                ("length", C.c_size_t), ("dimension", C.c_size_t)]
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("stream", C.c_void_p),
+                ("reorth", C.c_int), ("spmv_kernel", C.c_int), ("profile", C.c_int),
+                ("n_global", C.c_int64), ("row_begin", C.c_int64), ("n_ext", C.c_int64),
+                ("x_ext", C.c_void_p)]
+
+
+REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "mgs": 3, "full2": 4}
+SPMV = {"auto": 0, "vector": 1, "stream": 2}
+KERNEL_CLASSES = ("spmv", "recur", "scale", "dots", "update", "small")
+
+# ---- prototypes -----------------------------------------------------------
+_hip.lanczos_hip_crs.argtypes = [C.POINTER(Mat_Crs), _dp, C.c_void_p, C.c_int, C.c_int, C.c_double]
+_hip.lanczos_hip_crs.restype = C.c_int
+_hip.lanczos_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int,
+                                    C.POINTER(Options)]
+_hip.lanczos_hip_create.restype = C.c_int
+_hip.lanczos_hip_destroy.argtypes = [C.c_void_p]
+_hip.lanczos_hip_destroy.restype = None
+_hip.lanczos_hip_set_start.argtypes = [C.c_void_p, _dp]
+_hip.lanczos_hip_set_start.restype = C.c_int
+_hip.lanczos_hip_set_start_scaled.argtypes = [C.c_void_p, _dp, C.c_double]
+_hip.lanczos_hip_set_start_scaled.restype = C.c_int
+_hip.lanczos_hip_set_start_seed.argtypes = [C.c_void_p, C.c_uint64]
+_hip.lanczos_hip_set_start_seed.restype = C.c_int
+_hip.lanczos_hip_gaussian_fill.argtypes = [C.c_uint64, C.c_int64, C.c_int64, _dp]
+_hip.lanczos_hip_gaussian_fill.restype = None
+_hip.lanczos_hip_run.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+_hip.lanczos_hip_run.restype = C.c_int
+_hip.lanczos_hip_iterations.argtypes = [C.c_void_p]
+_hip.lanczos_hip_iterations.restype = C.c_int
+_hip.lanczos_hip_spmv.argtypes = [C.c_void_p, _dp, _dp]
+_hip.lanczos_hip_spmv.restype = C.c_int
+_hip.lanczos_hip_get_vector.argtypes = [C.c_void_p, C.c_int, _dp]
+_hip.lanczos_hip_get_vector.restype = C.c_int
+_hip.lanczos_hip_profile.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp]
+_hip.lanczos_hip_profile.restype = C.c_int
+_hip.lanczos_hip_profile_reset.argtypes = [C.c_void_p]
+_hip.lanczos_hip_profile_reset.restype = None
+_hip.lanczos_hip_spmv_name.argtypes = [C.c_void_p]
+_hip.lanczos_hip_spmv_name.restype = C.c_char_p
+_hip.lanczos_hip_tridiag_eigs.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
+_hip.lanczos_hip_tridiag_eigs.restype = C.c_int
+_hip.lanczos_hip_last_error.argtypes = []
+_hip.lanczos_hip_last_error.restype = C.c_char_p
+for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip_phase_scale"):
+    getattr(_hip, _name).argtypes = [C.c_void_p, C.c_void_p]
+    getattr(_hip, _name).restype = C.c_int
+_hip.lanczos_hip_phase_recur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+_hip.lanczos_hip_phase_recur.restype = C.c_int
+_hip.lanczos_hip_local_vector.argtypes = [C.c_void_p, C.c_int]
+_hip.lanczos_hip_local_vector.restype = C.c_void_p
+_hip.lanczos_hip_history.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
+_hip.lanczos_hip_history.restype = C.c_int
+
+_host.read_mat_coo_incremental.argtypes = [C.c_char_p]
+_host.read_mat_coo_incremental.restype = Mat_Coo
+_host.parse_to_coo.argtypes = [C.c_char_p, C.POINTER(Coo)]
+_host.parse_to_coo.restype = None
+_host.convert_from_coo.argtypes = [C.POINTER(Mat_Coo), C.c_int]
+_host.convert_from_coo.restype = Mat_Crs
+_host.matvec_crs.argtypes = [C.POINTER(Mat_Crs), _dp, _dp]
+_host.matvec_crs.restype = None
+_host.matvec_coo.argtypes = [C.POINTER(Mat_Coo), _dp, _dp]
+_host.matvec_coo.restype = None
+_host.lanczos_synth_laplacian.argtypes = [C.c_int, C.c_int64, C.POINTER(Mat_Crs)]
+_host.lanczos_synth_laplacian.restype = C.c_int
+_host.lanczos_synth_random_symmetric.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.POINTER(Mat_Crs)]
+_host.lanczos_synth_random_symmetric.restype = C.c_int
+_host.lanczos_free_crs.argtypes = [C.POINTER(Mat_Crs)]
+_host.lanczos_free_crs.restype = None
+_libc = C.CDLL(None)
+_libc.free.argtypes = [C.c_void_p]
+
+
+class LanczosHipError(RuntimeError):
+    pass
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise LanczosHipError(f"{what}: {_hip.lanczos_hip_last_error().decode(errors='replace')}")
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+# ---- host API kept from the reference ---------------------------------------
+class CrsMatrix:
+    """numpy view of a Mat_Crs (values, column_index, row_head_indexes)."""
+
+    def __init__(self, values, column_index, row_head_indexes):
+        self.values = _f64(values)
+        self.column_index = _i64(column_index)
+        self.row_head_indexes = _i64(row_head_indexes)
+        self.dimension = self.row_head_indexes.shape[0] - 1
+        self.length = self.values.shape[0]
+
+    def as_struct(self) -> Mat_Crs:
+        return Mat_Crs(self.values.ctypes.data_as(_dp), self.column_index.ctypes.data_as(_ip),
+                       self.row_head_indexes.ctypes.data_as(_ip), self.length, self.dimension)
+
+    @staticmethod
+    def _take(m: Mat_Crs) -> "CrsMatrix":
+        n, nnz = int(m.dimension), int(m.length)
+        out = CrsMatrix(np.ctypeslib.as_array(m.values, (nnz,)).copy() if nnz else np.zeros(0),
+                        np.ctypeslib.as_array(m.column_index, (nnz,)).copy() if nnz else np.zeros(0, np.int64),
+                        np.ctypeslib.as_array(m.row_head_indexes, (n + 1,)).copy())
+        _host.lanczos_free_crs(C.byref(m))
+        return out
+
+
+def read_mat_coo_incremental(path: str):
+    """-> (structured array of Coo, dimension); exits the process on malformed input, as the reference."""
+    m = _host.read_mat_coo_incremental(os.fsencode(path))
+    n = int(m.length)
+    arr = np.zeros(n, COO_DTYPE)
+    if n:
+        C.memmove(arr.ctypes.data, m.data, n * COO_DTYPE.itemsize)
+        _libc.free(C.cast(m.data, C.c_void_p))
+    return arr, int(m.dimension)
+
+
+def parse_to_coo(line: str):
+    c = Coo(0, 0, 0.0)
+    _host.parse_to_coo(C.create_string_buffer(line.encode()), C.byref(c))
+    return c.index_row, c.index_column, c.value
+
+
+def convert_from_coo(coo: np.ndarray, dimension: int, swap_row_column: int) -> CrsMatrix:
+    coo = np.ascontiguousarray(coo, dtype=COO_DTYPE)
+    m = Mat_Coo(C.cast(coo.ctypes.data, C.POINTER(Coo)), coo.shape[0], dimension)
+    return CrsMatrix._take(_host.convert_from_coo(C.byref(m), int(swap_row_column)))
+
+
+def matvec_crs(a: CrsMatrix, x) -> np.ndarray:
+    y = np.empty(a.dimension)
+    s = a.as_struct()
+    _host.matvec_crs(C.byref(s), _f64(x).ctypes.data_as(_dp), y.ctypes.data_as(_dp))
+    return y
+
+
+def synth_laplacian(d: int, N: int) -> CrsMatrix:
+    m = Mat_Crs()
+    if _host.lanczos_synth_laplacian(d, N, C.byref(m)) != 0:
+        raise ValueError(f"lanczos_synth_laplacian({d}, {N}) failed")
+    return CrsMatrix._take(m)
+
+
+def synth_random_symmetric(n: int, per_row: int, seed: int) -> CrsMatrix:
+    m = Mat_Crs()
+    if _host.lanczos_synth_random_symmetric(n, per_row, seed, C.byref(m)) != 0:
+        raise ValueError("lanczos_synth_random_symmetric failed")
+    return CrsMatrix._take(m)
+
+
+def gaussian_fill(seed: int, row_begin: int, n: int) -> np.ndarray:
+    out = np.empty(n)
+    _hip.lanczos_hip_gaussian_fill(seed, row_begin, n, out.ctypes.data_as(_dp))
+    return out
+
+
+def tridiag_eigs(alpha, beta, n: int, m: int) -> np.ndarray:
+    alpha, beta = _f64(alpha), _f64(beta if len(beta) else np.zeros(1))
+    eig = np.empty(m)
+    rc = _hip.lanczos_hip_tridiag_eigs(alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp), n, m,
+                                       eig.ctypes.data_as(_dp))
+    if rc != 0:
+        raise LanczosHipError("lanczos_hip_tridiag_eigs failed")
+    return eig
+
+
+# ---- solver entry points ----------------------------------------------------
+def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float) -> tuple[int, np.ndarray]:
+    """The drop-in entry; returns (status, eigenvalues[nth_eig])."""
+    eig = np.zeros(max(nth_eig, 1))
+    s = a.as_struct()
+    rc = _hip.lanczos_hip_crs(C.byref(s), eig.ctypes.data_as(_dp), None, nth_eig, max_iter, threshold)
+    return rc, eig[:max(nth_eig, 0)]
+
+
+class Engine:
+    """Handle API: one matrix resident on one GPU."""
+
+    def __init__(self, a: CrsMatrix, max_iter: int, reorth: str = "full", spmv: str = "auto",
+                 profile: bool = False, device: int = -1, stream: int | None = None,
+                 n_global: int = 0, row_begin: int = 0, n_ext: int = 0, x_ext: int | None = None):
+        self._h = C.c_void_p(None)
+        self.n = a.dimension
+        self.max_iter = max_iter
+        opt = Options(C.sizeof(Options), device, stream, REORTH[reorth], SPMV[spmv], int(profile),
+                      n_global, row_begin, n_ext, x_ext)
+        _check(_hip.lanczos_hip_create(C.byref(self._h), a.dimension, a.length,
+                                       a.row_head_indexes.ctypes.data_as(_ip),
+                                       a.column_index.ctypes.data_as(_ip),
+                                       a.values.ctypes.data_as(_dp), max_iter, C.byref(opt)),
+               "lanczos_hip_create")
+
+    def close(self):
+        if self._h:
+            _hip.lanczos_hip_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def spmv_name(self) -> str:
+        return _hip.lanczos_hip_spmv_name(self._h).decode()
+
+    @property
+    def iterations(self) -> int:
+        return _hip.lanczos_hip_iterations(self._h)
+
+    def set_start(self, v0):
+        v0 = _f64(v0)
+        assert v0.shape[0] == self.n
+        _check(_hip.lanczos_hip_set_start(self._h, v0.ctypes.data_as(_dp)), "lanczos_hip_set_start")
+
+    def set_start_scaled(self, v0, scale: float):
+        v0 = _f64(v0)
+        assert v0.shape[0] == self.n
+        _check(_hip.lanczos_hip_set_start_scaled(self._h, v0.ctypes.data_as(_dp), scale),
+               "lanczos_hip_set_start_scaled")
+
+    def set_start_seed(self, seed: int):
+        _check(_hip.lanczos_hip_set_start_seed(self._h, seed), "lanczos_hip_set_start_seed")
+
+    def run(self, steps: int):
+        alpha, beta = np.zeros(steps), np.zeros(steps)
+        _check(_hip.lanczos_hip_run(self._h, steps, alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp)),
+               "lanczos_hip_run")
+        return alpha, beta
+
+    def spmv(self, x, n_ext: int | None = None):
+        x = _f64(x)
+        y = np.empty(self.n)
+        _check(_hip.lanczos_hip_spmv(self._h, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)), "lanczos_hip_spmv")
+        return y
+
+    def get_vector(self, k: int):
+        out = np.empty(self.n)
+        _check(_hip.lanczos_hip_get_vector(self._h, k, out.ctypes.data_as(_dp)), "lanczos_hip_get_vector")
+        return out
+
+    def profile(self) -> dict:
+        out = {}
+        for i, name in enumerate(KERNEL_CLASSES):
+            ms, cnt, by = C.c_double(0), C.c_int64(0), C.c_double(0)
+            _check(_hip.lanczos_hip_profile(self._h, i, C.byref(ms), C.byref(cnt), C.byref(by)),
+                   "lanczos_hip_profile")
+            out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value}
+        return out
+
+    def profile_reset(self):
+        _hip.lanczos_hip_profile_reset(self._h)
+
+    # phase-level calls for row-partitioned runs; `red` is a device address
+    def phase_spmv(self, red: int):
+        _check(_hip.lanczos_hip_phase_spmv(self._h, red), "lanczos_hip_phase_spmv")
+
+    def phase_recur(self, red: int):
+        n_red, is_norm = C.c_int(0), C.c_int(0)
+        _check(_hip.lanczos_hip_phase_recur(self._h, red, C.byref(n_red), C.byref(is_norm)),
+               "lanczos_hip_phase_recur")
+        return n_red.value, bool(is_norm.value)
+
+    def phase_update(self, red: int):
+        _check(_hip.lanczos_hip_phase_update(self._h, red), "lanczos_hip_phase_update")
+
+    def phase_scale(self, red: int):
+        _check(_hip.lanczos_hip_phase_scale(self._h, red), "lanczos_hip_phase_scale")
+
+    def local_vector_ptr(self, k: int) -> int:
+        return _hip.lanczos_hip_local_vector(self._h, k)
+
+    def history(self, count: int):
+        alpha, beta = np.zeros(count), np.zeros(count)
+        _check(_hip.lanczos_hip_history(self._h, alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp), count),
+               "lanczos_hip_history")
+        return alpha, beta
+
+
+def ritz_values(alpha, beta, steps: int, nth: int) -> np.ndarray:
+    """Lowest nth Ritz values of the steps x steps tridiagonal matrix (host solve)."""
+    return tridiag_eigs(alpha[:steps], beta[:max(steps - 1, 0)], steps, nth)

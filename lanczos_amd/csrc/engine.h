@@ -1,0 +1,100 @@
+// Internal C++ view of the engine behind include/lanczos_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "../../include/lanczos_hip.h"
+
+namespace lz {
+
+constexpr int kMaxDotsSegment = 1024;  // basis vectors per k_dots launch (32 KiB of LDS)
+
+int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+const char *last_error();
+
+struct Engine {
+    // geometry
+    int64_t n = 0;         // local rows
+    int64_t n_ext = 0;     // length of the SpMV input vector
+    int64_t n_global = 0;
+    int64_t row_begin = 0;
+    int64_t nnz = 0;
+    int64_t ldv = 0;       // doubles between consecutive basis vectors (zero padded)
+    int max_iter = 0;
+    int nvec = 0;          // resident basis vectors (max_iter, or a ring of 3)
+    int reorth = 0;
+    int device = -1;
+    int cus = 0;
+    int max_blocks = 0;    // 8 workgroups per CU, multiple of 8
+    // device memory
+    void *d_rp = nullptr;  // int32 or int64 row offsets
+    bool rp64 = false;
+    int32_t *d_col = nullptr;
+    double *d_val = nullptr;
+    double *d_V = nullptr;
+    double *x_ext = nullptr;  // caller-owned gather buffer (row-partitioned use)
+    double *d_partials = nullptr;
+    double *d_hpart = nullptr;
+    int hstride = 0;
+    double *d_red = nullptr;   // [max_iter] reduction results (single-GPU runs)
+    double *d_scal = nullptr;  // [1] = beta of the previous iteration
+    double *d_alpha = nullptr, *d_beta = nullptr;
+    int hist_cap = 0;
+    double *h_hist = nullptr;  // pinned mirror {alpha_k, beta_k} for the pipelined host loop
+    // stream
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // SpMV variant
+    int spmv_kind = 0;
+    int group = 8;
+    char spmv_name[32] = "";
+    // iteration state
+    int k = 0;
+    bool started = false;
+    int recur_parts = 0;
+    // profiling
+    bool profile = false;
+    double prof_ms[LANCZOS_HIP_K_COUNT] = {0};
+    int64_t prof_launches[LANCZOS_HIP_K_COUNT] = {0};
+    double prof_bytes[LANCZOS_HIP_K_COUNT] = {0};
+    struct Pending { int cls; hipEvent_t start, stop; };
+    std::vector<Pending> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+
+    static int create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, const int64_t *ci,
+                      const double *va, int max_iter, const lanczos_hip_options *opt);
+    ~Engine();
+    int init(const lanczos_hip_options &opt, int64_t n, int64_t n_ext, int64_t nnz, const int64_t *rp,
+             const int64_t *ci, const double *va, int max_iter);
+
+    // basis slot of Lanczos vector j (a ring of 3 when nothing older is needed)
+    double *vec(int j) const { return d_V + (size_t)(reorth == LANCZOS_HIP_REORTH_NONE ? j % 3 : j) * (size_t)ldv; }
+    int vec_blocks() const;
+    int tile_blocks() const;
+    double spmv_bytes() const;
+
+    int set_start(const double *v0, bool normalise, double scale);
+    int check_can_step();
+    void reorth_range(int *l0, int *l1) const;
+    int launch_spmv(const double *x, const double *xdot, double *y, int *nparts);
+    int launch_finalize(int nparts, double *out);
+    int launch_recur(const double *alpha_p);
+    int launch_dots(int l0, int l1, double *red_out);
+    int launch_update(int l0, int l1, const double *h, int *nparts);
+    int phase_spmv(double *red);
+    int phase_recur(double *red, int *n_red, int *is_norm);
+    int phase_dots(double *red, int *n_red);
+    int phase_update(double *red);
+    int phase_scale(double *red);
+    int enqueue_iteration();
+    int run(int steps, double *alpha_out, double *beta_out);
+    int spmv_host(const double *x_host, double *y_host);
+    int enable_host_history();
+
+    hipEvent_t take_event();
+    void harvest_profile();
+};
+
+}  // namespace lz

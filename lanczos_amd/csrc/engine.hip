@@ -1,0 +1,659 @@
+// Host side of the HIP Lanczos engine: device memory, kernel launches, the
+// iteration phases and the extern "C" entry points declared in
+// include/lanczos_hip.h.  One engine = one GPU = one stream; nothing here
+// synchronises with the host inside an iteration.
+#include "engine.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "kernels.hip.h"
+
+namespace lz {
+
+static thread_local char g_err[512] = "";
+
+int fail(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    printf("%s\n", g_err);  // stdout, as the reference's CHECK_*_GOTO macros (src/lanczos_cuda.h:76-124)
+    return EXIT_FAILURE;
+}
+
+const char *last_error() { return g_err; }
+
+#define HIP_TRY(call)                                                                         \
+    do {                                                                                      \
+        hipError_t st__ = (call);                                                             \
+        if (st__ != hipSuccess)                                                               \
+            return fail("HIP API failed at %s:%d with error: %s (%d)", __FILE__, __LINE__,    \
+                        hipGetErrorString(st__), (int)st__);                                  \
+    } while (0)
+
+static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// profiling helpers
+// ---------------------------------------------------------------------------
+struct ProfScope {
+    Engine *e;
+    int cls;
+    ProfScope(Engine *eng, int c, double bytes) : e(eng), cls(c) {
+        if (!e->profile) return;
+        e->prof_bytes[cls] += bytes;
+        e->prof_launches[cls] += 1;
+        hipEvent_t a = e->take_event();
+        (void)hipEventRecord(a, e->stream);
+        e->prof_pending.push_back({cls, a, nullptr});
+    }
+    ~ProfScope() {
+        if (!e->profile) return;
+        hipEvent_t b = e->take_event();
+        (void)hipEventRecord(b, e->stream);
+        e->prof_pending.back().stop = b;
+    }
+};
+
+hipEvent_t Engine::take_event() {
+    if (!event_pool.empty()) {
+        hipEvent_t ev = event_pool.back();
+        event_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+void Engine::harvest_profile() {
+    for (auto &p : prof_pending) {
+        float ms = 0.f;
+        if (p.start && p.stop && hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess)
+            prof_ms[p.cls] += ms;
+        if (p.start) event_pool.push_back(p.start);
+        if (p.stop) event_pool.push_back(p.stop);
+    }
+    prof_pending.clear();
+}
+
+// ---------------------------------------------------------------------------
+// creation / destruction
+// ---------------------------------------------------------------------------
+static int pick_group(double mean_nnz) {
+    int g = 2;
+    while (g < 64 && g < mean_nnz) g <<= 1;
+    return g;
+}
+
+int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, const int64_t *ci,
+                   const double *va, int max_iter, const lanczos_hip_options *opt_in) {
+    *out = nullptr;
+    lanczos_hip_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.device = -1;
+    if (opt_in) memcpy(&opt, opt_in, std::min(sizeof(opt), opt_in->struct_size));
+    if (n <= 0 || nnz < 0 || !rp || (nnz > 0 && (!ci || !va)))
+        return fail("lanczos_hip_create: NULL or empty matrix (n=%lld, nnz=%lld)", (long long)n, (long long)nnz);
+    if (n > (int64_t)INT32_MAX)
+        return fail("Matrix dimension too large for HIP CRS (dim=%lld)", (long long)n);
+    if (max_iter < 2) return fail("max_iter must be >= 2");
+    const bool dist = opt.x_ext != nullptr;
+    const int64_t n_ext = dist ? opt.n_ext : n;
+    if (dist && (n_ext <= 0 || n_ext > (int64_t)INT32_MAX))
+        return fail("lanczos_hip_create: bad n_ext=%lld", (long long)n_ext);
+    // The kernels trust these arrays; check them here, once, on the host.
+    if (rp[0] != 0 || rp[n] != nnz)
+        return fail("lanczos_hip_create: row_head_indexes[0]=%lld, [n]=%lld, nnz=%lld", (long long)rp[0],
+                    (long long)rp[n], (long long)nnz);
+    int bad = 0;
+    for (int64_t i = 0; i < n; i++) bad |= (rp[i + 1] < rp[i]);
+    if (bad) return fail("lanczos_hip_create: row_head_indexes not monotone");
+    for (int64_t j = 0; j < nnz; j++) bad |= (ci[j] < 0 || ci[j] >= n_ext);
+    if (bad) return fail("lanczos_hip_create: column index out of range [0, %lld)", (long long)n_ext);
+
+    Engine *e = new Engine();
+    int rc = e->init(opt, n, n_ext, nnz, rp, ci, va, max_iter);
+    if (rc != 0) {
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return 0;
+}
+
+int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int64_t nnz_,
+                 const int64_t *rp, const int64_t *ci, const double *va, int max_iter_) {
+    n = n_;
+    n_ext = n_ext_;
+    nnz = nnz_;
+    max_iter = max_iter_;
+    reorth = opt.reorth;
+    profile = opt.profile != 0;
+    x_ext = opt.x_ext;
+    n_global = opt.n_global ? opt.n_global : n;
+    row_begin = opt.row_begin;
+    if (reorth < 0 || reorth > LANCZOS_HIP_REORTH_FULL2) return fail("lanczos_hip_create: bad reorth mode %d", reorth);
+    if (opt.device >= 0) {
+        HIP_TRY(hipSetDevice(opt.device));
+        device = opt.device;
+    } else {
+        HIP_TRY(hipGetDevice(&device));
+    }
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail("lanczos_hip: device %d is %s; this library holds gfx950 code only", device, prop.gcnArchName);
+    cus = prop.multiProcessorCount;
+    max_blocks = cus * 8;
+    max_blocks -= max_blocks % 8;
+    if (opt.stream) {
+        stream = (hipStream_t)opt.stream;
+        own_stream = false;
+    } else {
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        own_stream = true;
+    }
+
+    // ---- matrix upload: values as they are, columns narrowed on the device,
+    //      row offsets narrowed on the host when they fit 32 bits
+    rp64 = nnz >= ((int64_t)1 << 31);
+    HIP_TRY(hipMalloc(&d_val, sizeof(double) * std::max<int64_t>(nnz, 1)));
+    HIP_TRY(hipMalloc(&d_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    HIP_TRY(hipMalloc(&d_rp, (rp64 ? 8 : 4) * (n + 1)));
+    if (nnz > 0) {
+        HIP_TRY(hipMemcpyAsync(d_val, va, sizeof(double) * nnz, hipMemcpyHostToDevice, stream));
+        const int64_t chunk = (int64_t)1 << 26;  // 512 MiB of int64 per piece
+        int64_t *stage = nullptr;
+        HIP_TRY(hipMalloc(&stage, sizeof(int64_t) * std::min(chunk, nnz)));
+        for (int64_t off = 0; off < nnz; off += chunk) {
+            const int64_t cnt = std::min(chunk, nnz - off);
+            HIP_TRY(hipMemcpyAsync(stage, ci + off, sizeof(int64_t) * cnt, hipMemcpyHostToDevice, stream));
+            const int blocks = (int)std::min<int64_t>(max_blocks, (cnt + kBlock - 1) / kBlock);
+            hipLaunchKernelGGL(k_narrow_i64, dim3(blocks), dim3(kBlock), 0, stream, stage, d_col + off, cnt);
+        }
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipFree(stage));
+    }
+    if (rp64) {
+        HIP_TRY(hipMemcpyAsync(d_rp, rp, 8 * (n + 1), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    } else {
+        std::vector<int32_t> rp32((size_t)n + 1);
+        for (int64_t i = 0; i <= n; i++) rp32[(size_t)i] = (int32_t)rp[i];
+        HIP_TRY(hipMemcpyAsync(d_rp, rp32.data(), 4 * (n + 1), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+
+    // ---- SpMV variant
+    const double mean = (double)nnz / (double)n;
+    spmv_kind = opt.spmv_kernel;
+    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) spmv_kind = LANCZOS_HIP_SPMV_STREAM;
+    group = pick_group(mean);
+    if (spmv_kind == LANCZOS_HIP_SPMV_STREAM)
+        snprintf(spmv_name, sizeof(spmv_name), "stream%s", rp64 ? "_rp64" : "");
+    else
+        snprintf(spmv_name, sizeof(spmv_name), "vector%d%s", group, rp64 ? "_rp64" : "");
+
+    // ---- Krylov basis: every vector padded with zeros to whole tiles
+    ldv = round_up(n, 2 * kTileV2);
+    nvec = (reorth == LANCZOS_HIP_REORTH_NONE) ? 3 : max_iter;
+    const size_t vbytes = sizeof(double) * (size_t)ldv * (size_t)nvec;
+    HIP_TRY(hipMalloc(&d_V, vbytes));
+    HIP_TRY(hipMemsetAsync(d_V, 0, vbytes, stream));
+
+    // ---- small buffers
+    HIP_TRY(hipMalloc(&d_partials, sizeof(double) * max_blocks));
+    hstride = max_blocks;
+    const int hl = std::min(max_iter, kMaxDotsSegment);
+    HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)hstride * (size_t)hl));
+    HIP_TRY(hipMalloc(&d_red, sizeof(double) * (size_t)std::max(max_iter, 8)));
+    HIP_TRY(hipMalloc(&d_scal, sizeof(double) * 8));
+    HIP_TRY(hipMemsetAsync(d_scal, 0, sizeof(double) * 8, stream));
+    hist_cap = (reorth == LANCZOS_HIP_REORTH_NONE) ? std::max(max_iter, 1 << 16) : max_iter;
+    HIP_TRY(hipMalloc(&d_alpha, sizeof(double) * hist_cap));
+    HIP_TRY(hipMalloc(&d_beta, sizeof(double) * hist_cap));
+    HIP_TRY(hipMemsetAsync(d_alpha, 0, sizeof(double) * hist_cap, stream));
+    HIP_TRY(hipMemsetAsync(d_beta, 0, sizeof(double) * hist_cap, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    k = 0;
+    started = false;
+    return 0;
+}
+
+Engine::~Engine() {
+    if (device >= 0) (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize(stream);
+    harvest_profile();
+    for (auto ev : event_pool) (void)hipEventDestroy(ev);
+    (void)hipFree(d_val);
+    (void)hipFree(d_col);
+    (void)hipFree(d_rp);
+    (void)hipFree(d_V);
+    (void)hipFree(d_partials);
+    (void)hipFree(d_hpart);
+    (void)hipFree(d_red);
+    (void)hipFree(d_scal);
+    (void)hipFree(d_alpha);
+    (void)hipFree(d_beta);
+    if (h_hist) (void)hipHostFree(h_hist);
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+}
+
+// ---------------------------------------------------------------------------
+// launches
+// ---------------------------------------------------------------------------
+int Engine::vec_blocks() const {
+    const int64_t n2 = ldv / 2;
+    return (int)std::min<int64_t>(max_blocks, (n2 + kBlock - 1) / kBlock);
+}
+
+int Engine::tile_blocks() const {
+    const int64_t tiles = (ldv / 2) / kTileV2;
+    return (int)std::min<int64_t>(max_blocks, std::max<int64_t>(tiles, 1));
+}
+
+double Engine::spmv_bytes() const {
+    return 12.0 * (double)nnz + (rp64 ? 8.0 : 4.0) * (double)(n + 1) + 8.0 * (double)n_ext + 8.0 * (double)n;
+}
+
+template <typename RP>
+static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double *y, int *nparts) {
+    const RP *rp = (const RP *)e->d_rp;
+    if (e->spmv_kind == LANCZOS_HIP_SPMV_STREAM) {
+        const int64_t groups = (e->n + 63) / 64;
+        const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+        int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
+        *nparts = blocks;
+        hipLaunchKernelGGL((k_spmv_stream<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp, e->d_col,
+                           e->d_val, x, xdot, y, e->d_partials);
+        return;
+    }
+#define LZ_VEC_CASE(G)                                                                                        \
+    case G: {                                                                                                 \
+        const int64_t chunks = (e->n + (kBlock / G) - 1) / (kBlock / G);                                      \
+        int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));                              \
+        *nparts = blocks;                                                                                     \
+        hipLaunchKernelGGL((k_spmv_vector<G, RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp,       \
+                           e->d_col, e->d_val, x, xdot, y, e->d_partials);                                    \
+    } break;
+    switch (e->group) {
+        LZ_VEC_CASE(2)
+        LZ_VEC_CASE(4)
+        LZ_VEC_CASE(8)
+        LZ_VEC_CASE(16)
+        LZ_VEC_CASE(32)
+        default:
+            LZ_VEC_CASE(64)
+    }
+#undef LZ_VEC_CASE
+}
+
+int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *nparts) {
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
+    if (rp64)
+        launch_spmv_t<int64_t>(this, x, xdot, y, nparts);
+    else
+        launch_spmv_t<int32_t>(this, x, xdot, y, nparts);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::launch_finalize(int nparts, double *out) {
+    ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * nparts);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_partials, nparts, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::launch_dots(int l0, int l1, double *red_out) {
+    // red_out[l - l0] = V_l . w  for l in [l0, l1), w = vec(k+1)
+    const int blocks = tile_blocks();
+    for (int s0 = l0; s0 < l1; s0 += kMaxDotsSegment) {
+        const int s1 = std::min(l1, s0 + kMaxDotsSegment);
+        const int nl = s1 - s0;
+        {
+            ProfScope ps(this, LANCZOS_HIP_K_DOTS, 8.0 * (double)n * nl + 8.0 * (double)n);
+            hipLaunchKernelGGL(k_dots, dim3(blocks), dim3(kBlock), sizeof(double) * kWavesPerBlock * nl, stream,
+                               (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), ldv / 2,
+                               d_hpart, hstride);
+        }
+        {
+            ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (double)blocks * nl);
+            hipLaunchKernelGGL(k_hreduce, dim3(nl), dim3(kBlock), 0, stream, d_hpart, hstride, blocks,
+                               red_out + (s0 - l0));
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
+    const int blocks = tile_blocks();
+    *nparts = blocks;
+    ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (l1 - l0) + 16.0 * (double)n);
+    hipLaunchKernelGGL(k_update, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
+                       (double2 *)vec(k + 1), ldv / 2, h, d_partials);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// start vector
+// ---------------------------------------------------------------------------
+int Engine::set_start(const double *v0, bool normalise, double scale) {
+    if (!v0) return fail("lanczos_hip_set_start: NULL vector");
+    HIP_TRY(hipSetDevice(device));
+    // clear every slot: a second run must not see the previous basis
+    HIP_TRY(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)ldv * (size_t)nvec, stream));
+    HIP_TRY(hipMemcpyAsync(vec(0), v0, sizeof(double) * n, hipMemcpyHostToDevice, stream));
+    const int blocks = vec_blocks();
+    if (normalise) {
+        hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)vec(0),
+                           (const double2 *)vec(0), ldv / 2, d_partials);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_partials, blocks, d_red);
+        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), ldv / 2,
+                           (const double *)d_red, 0.0);
+    } else {
+        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), ldv / 2,
+                           (const double *)nullptr, scale);
+    }
+    HIP_TRY(hipMemsetAsync(d_scal, 0, sizeof(double) * 8, stream));
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(stream));  // v0 may be pageable host memory
+    k = 0;
+    started = true;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// iteration phases
+// ---------------------------------------------------------------------------
+int Engine::check_can_step() {
+    if (!started) return fail("lanczos_hip: no start vector set");
+    if (reorth != LANCZOS_HIP_REORTH_NONE && k >= max_iter - 1)
+        return fail("lanczos_hip: basis full (%d iterations of max_iter=%d done)", k, max_iter);
+    if (k >= hist_cap) return fail("lanczos_hip: history full (%d iterations)", k);
+    return 0;
+}
+
+void Engine::reorth_range(int *l0, int *l1) const {
+    *l0 = 0;
+    switch (reorth) {
+        case LANCZOS_HIP_REORTH_NONE: *l1 = 0; break;
+        case LANCZOS_HIP_REORTH_CUDA_COMPAT: *l1 = k - 2; break;
+        default: *l1 = k; break;
+    }
+    if (*l1 < 0) *l1 = 0;
+}
+
+int Engine::phase_spmv(double *red) {
+    if (int rc = check_can_step()) return rc;
+    const double *x = x_ext ? x_ext : vec(k);
+    int nparts = 0;
+    if (int rc = launch_spmv(x, vec(k), vec(k + 1), &nparts)) return rc;
+    return launch_finalize(nparts, red);
+}
+
+int Engine::launch_recur(const double *alpha_p) {
+    const int blocks = vec_blocks();
+    recur_parts = blocks;
+    ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
+    double *ahost = h_hist ? h_hist + 2 * (size_t)k : nullptr;
+    hipLaunchKernelGGL(k_recur, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
+                       (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, alpha_p,
+                       (const double *)(d_scal + 1), d_partials, d_alpha + k, ahost);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
+    // red[0] holds alpha (already reduced over ranks by the caller)
+    if (int rc = launch_recur(red)) return rc;
+    int l0, l1;
+    reorth_range(&l0, &l1);
+    if (l1 - l0 <= 0) {
+        *n_red = 1;
+        *is_norm = 1;
+        return launch_finalize(recur_parts, red);
+    }
+    *n_red = l1 - l0;
+    *is_norm = 0;
+    return launch_dots(l0, l1, red);
+}
+
+int Engine::phase_dots(double *red, int *n_red) {
+    int l0, l1;
+    reorth_range(&l0, &l1);
+    *n_red = l1 - l0;
+    if (*n_red <= 0) return fail("lanczos_hip_phase_dots: empty range");
+    return launch_dots(l0, l1, red);
+}
+
+int Engine::phase_update(double *red) {
+    int l0, l1;
+    reorth_range(&l0, &l1);
+    if (l1 - l0 <= 0) return fail("lanczos_hip_phase_update: empty range");
+    // k_update reads the coefficients from `red`; the finaliser that then
+    // overwrites red[0] is ordered behind it on the stream
+    int nparts = 0;
+    if (int rc = launch_update(l0, l1, red, &nparts)) return rc;
+    return launch_finalize(nparts, red);
+}
+
+int Engine::phase_scale(double *red) {
+    const int blocks = vec_blocks();
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SCALE, 16.0 * (double)n);
+        double *bhost = h_hist ? h_hist + 2 * (size_t)k + 1 : nullptr;
+        hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1), ldv / 2,
+                           (const double *)red, d_scal + 1, d_beta + k, bhost);
+    }
+    HIP_TRY(hipGetLastError());
+    k += 1;
+    return 0;
+}
+
+// One whole iteration on a single GPU (no cross-rank reduction in between).
+int Engine::enqueue_iteration() {
+    if (int rc = phase_spmv(d_red)) return rc;
+    if (reorth == LANCZOS_HIP_REORTH_MGS) {
+        // exact order of src/lanczos.c:156-167: one basis vector at a time
+        if (int rc = launch_recur(d_red)) return rc;
+        int nparts = recur_parts;
+        for (int l = 0; l < k; ++l) {
+            if (int rc = launch_dots(l, l + 1, d_red + 1)) return rc;
+            if (int rc = launch_update(l, l + 1, d_red + 1, &nparts)) return rc;
+        }
+        if (int rc = launch_finalize(nparts, d_red)) return rc;
+        return phase_scale(d_red);
+    }
+    int n_red = 0, is_norm = 0;
+    if (int rc = phase_recur(d_red, &n_red, &is_norm)) return rc;
+    if (!is_norm) {
+        if (int rc = phase_update(d_red)) return rc;
+        if (reorth == LANCZOS_HIP_REORTH_FULL2) {
+            if (int rc = phase_dots(d_red, &n_red)) return rc;
+            if (int rc = phase_update(d_red)) return rc;
+        }
+    }
+    return phase_scale(d_red);
+}
+
+int Engine::run(int steps, double *alpha_out, double *beta_out) {
+    if (steps < 0) return fail("lanczos_hip_run: steps=%d", steps);
+    HIP_TRY(hipSetDevice(device));
+    const int k0 = k;
+    for (int s = 0; s < steps; ++s)
+        if (int rc = enqueue_iteration()) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    harvest_profile();
+    if (alpha_out && steps)
+        HIP_TRY(hipMemcpy(alpha_out, d_alpha + k0, sizeof(double) * steps, hipMemcpyDeviceToHost));
+    if (beta_out && steps)
+        HIP_TRY(hipMemcpy(beta_out, d_beta + k0, sizeof(double) * steps, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int Engine::spmv_host(const double *x_host, double *y_host) {
+    if (!x_host || !y_host) return fail("lanczos_hip_spmv: NULL argument");
+    HIP_TRY(hipSetDevice(device));
+    double *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc(&dx, sizeof(double) * n_ext));
+    HIP_TRY(hipMalloc(&dy, sizeof(double) * n));
+    HIP_TRY(hipMemcpyAsync(dx, x_host, sizeof(double) * n_ext, hipMemcpyHostToDevice, stream));
+    int nparts = 0;
+    // xdot only feeds the alpha partial; any n-vector will do here
+    int rc = launch_spmv(dx, dy, dy, &nparts);
+    if (rc == 0) {
+        hipError_t st = hipMemcpyAsync(y_host, dy, sizeof(double) * n, hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);
+        if (st != hipSuccess) rc = fail("lanczos_hip_spmv: %s", hipGetErrorString(st));
+    }
+    harvest_profile();
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return rc;
+}
+
+int Engine::enable_host_history() {
+    if (h_hist) return 0;
+    HIP_TRY(hipHostMalloc((void **)&h_hist, sizeof(double) * 2 * (size_t)hist_cap, hipHostMallocDefault));
+    memset(h_hist, 0, sizeof(double) * 2 * (size_t)hist_cap);
+    return 0;
+}
+
+}  // namespace lz
+
+// ---------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------
+using lz::Engine;
+
+static Engine *E(lanczos_hip_engine *e) { return reinterpret_cast<Engine *>(e); }
+static const Engine *E(const lanczos_hip_engine *e) { return reinterpret_cast<const Engine *>(e); }
+
+extern "C" {
+
+int lanczos_hip_create(lanczos_hip_engine **out, int64_t n, int64_t nnz, const int64_t *row_head_indexes,
+                       const int64_t *column_index, const double *values, int max_iter,
+                       const lanczos_hip_options *opt) {
+    if (!out) return lz::fail("lanczos_hip_create: NULL out");
+    Engine *e = nullptr;
+    int rc = Engine::create(&e, n, nnz, row_head_indexes, column_index, values, max_iter, opt);
+    *out = reinterpret_cast<lanczos_hip_engine *>(e);
+    return rc;
+}
+
+void lanczos_hip_destroy(lanczos_hip_engine *e) { delete E(e); }
+
+int lanczos_hip_set_start(lanczos_hip_engine *e, const double *v0_host) {
+    if (!e) return lz::fail("lanczos_hip_set_start: NULL engine");
+    return E(e)->set_start(v0_host, true, 1.0);
+}
+
+int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, double scale) {
+    if (!e) return lz::fail("lanczos_hip_set_start_scaled: NULL engine");
+    return E(e)->set_start(v0_host, false, scale);
+}
+
+int lanczos_hip_set_start_seed(lanczos_hip_engine *e, uint64_t seed) {
+    if (!e) return lz::fail("lanczos_hip_set_start_seed: NULL engine");
+    Engine *g = E(e);
+    if (g->x_ext) return lz::fail("lanczos_hip_set_start_seed: row-partitioned engines need a global norm; use lanczos_hip_gaussian_fill + lanczos_hip_set_start_scaled");
+    std::vector<double> v((size_t)g->n);
+    lanczos_hip_gaussian_fill(seed, g->row_begin, g->n, v.data());
+    return g->set_start(v.data(), true, 1.0);
+}
+
+int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out) {
+    if (!e) return lz::fail("lanczos_hip_run: NULL engine");
+    if (E(e)->x_ext) return lz::fail("lanczos_hip_run: row-partitioned engines are driven phase by phase");
+    return E(e)->run(steps, alpha_out, beta_out);
+}
+
+int lanczos_hip_iterations(const lanczos_hip_engine *e) { return e ? E(e)->k : 0; }
+
+int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host) {
+    if (!e) return lz::fail("lanczos_hip_spmv: NULL engine");
+    return E(e)->spmv_host(x_host, y_host);
+}
+
+int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host) {
+    if (!e || !out_host) return lz::fail("lanczos_hip_get_vector: NULL argument");
+    Engine *g = E(e);
+    if (k < 0 || k > g->k || (g->reorth == LANCZOS_HIP_REORTH_NONE && k + 2 < g->k))
+        return lz::fail("lanczos_hip_get_vector: vector %d is not resident (iteration %d)", k, g->k);
+    if (hipSetDevice(g->device) != hipSuccess) return lz::fail("lanczos_hip_get_vector: hipSetDevice failed");
+    hipError_t st = hipMemcpyAsync(out_host, g->vec(k), sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(g->stream);
+    if (st != hipSuccess) return lz::fail("lanczos_hip_get_vector: %s", hipGetErrorString(st));
+    return 0;
+}
+
+int lanczos_hip_profile(const lanczos_hip_engine *e, int cls, double *ms, int64_t *launches, double *bytes) {
+    if (!e || cls < 0 || cls >= LANCZOS_HIP_K_COUNT) return lz::fail("lanczos_hip_profile: bad argument");
+    if (ms) *ms = E(e)->prof_ms[cls];
+    if (launches) *launches = E(e)->prof_launches[cls];
+    if (bytes) *bytes = E(e)->prof_bytes[cls];
+    return 0;
+}
+
+void lanczos_hip_profile_reset(lanczos_hip_engine *e) {
+    if (!e) return;
+    Engine *g = E(e);
+    g->harvest_profile();
+    for (int i = 0; i < LANCZOS_HIP_K_COUNT; ++i) {
+        g->prof_ms[i] = 0;
+        g->prof_launches[i] = 0;
+        g->prof_bytes[i] = 0;
+    }
+}
+
+const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e) { return e ? E(e)->spmv_name : ""; }
+
+const char *lanczos_hip_last_error(void) { return lz::last_error(); }
+
+int lanczos_hip_phase_spmv(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_spmv: NULL argument");
+    return E(e)->phase_spmv(red);
+}
+int lanczos_hip_phase_recur(lanczos_hip_engine *e, double *red, int *n_red, int *is_norm) {
+    if (!e || !red || !n_red || !is_norm) return lz::fail("lanczos_hip_phase_recur: NULL argument");
+    return E(e)->phase_recur(red, n_red, is_norm);
+}
+int lanczos_hip_phase_update(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_update: NULL argument");
+    return E(e)->phase_update(red);
+}
+int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_scale: NULL argument");
+    return E(e)->phase_scale(red);
+}
+double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k) {
+    if (!e || k < 0) return nullptr;
+    return E(e)->vec(k);
+}
+int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_out, int count) {
+    if (!e) return lz::fail("lanczos_hip_history: NULL engine");
+    Engine *g = E(e);
+    if (count < 0 || count > g->k) return lz::fail("lanczos_hip_history: count=%d of %d", count, g->k);
+    if (hipSetDevice(g->device) != hipSuccess) return lz::fail("lanczos_hip_history: hipSetDevice failed");
+    hipError_t st = hipStreamSynchronize(g->stream);
+    g->harvest_profile();
+    if (st == hipSuccess && alpha_out && count)
+        st = hipMemcpy(alpha_out, g->d_alpha, sizeof(double) * count, hipMemcpyDeviceToHost);
+    if (st == hipSuccess && beta_out && count)
+        st = hipMemcpy(beta_out, g->d_beta, sizeof(double) * count, hipMemcpyDeviceToHost);
+    if (st != hipSuccess) return lz::fail("lanczos_hip_history: %s", hipGetErrorString(st));
+    return 0;
+}
+
+}  // extern "C"

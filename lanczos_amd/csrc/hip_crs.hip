@@ -1,0 +1,183 @@
+// lanczos_hip_crs(): the drop-in for lanczos_cuda_crs (reference
+// src/lanczos_cuda.c:281-788) with the termination rules of the CPU solver
+// (src/lanczos.c:104-191), which is the parity target.
+//
+// The GPU never waits for the host: iterations are enqueued a few ahead of the
+// one whose alpha/beta the host is looking at, the two scalars of every
+// iteration land in pinned host memory straight from the kernels that produce
+// them, and the host solves the small tridiagonal eigenproblem while the next
+// iterations run.  Stopping early only discards the iterations in flight.
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <chrono>
+#include <vector>
+
+#include "engine.h"
+
+namespace {
+
+double now_sec() {
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+int env_int(const char *name, int dflt) {
+    const char *s = getenv(name);
+    return (s && *s) ? atoi(s) : dflt;
+}
+
+int env_reorth() {
+    const char *s = getenv("LANCZOS_HIP_REORTH");
+    if (!s || !*s || !strcmp(s, "full")) return LANCZOS_HIP_REORTH_FULL;
+    if (!strcmp(s, "full2")) return LANCZOS_HIP_REORTH_FULL2;
+    if (!strcmp(s, "mgs")) return LANCZOS_HIP_REORTH_MGS;
+    if (!strcmp(s, "cuda_compat")) return LANCZOS_HIP_REORTH_CUDA_COMPAT;
+    if (!strcmp(s, "none")) return LANCZOS_HIP_REORTH_NONE;
+    return -1;
+}
+
+}  // namespace
+
+extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[], int nth_eig,
+                               int max_iter, double threshold) {
+    (void)eigenvectors;  // neither reference solver fills them (src/lanczos.c:20, src/lanczos_cuda.c:284)
+    if (mat == NULL || eigenvalues == NULL) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
+    if (mat->dimension > (size_t)INT_MAX) {                       // src/lanczos_cuda.c:319-322
+        printf("Matrix dimension too large for HIP CRS (dim=%zu)\n", mat->dimension);
+        return EXIT_FAILURE;
+    }
+    if (max_iter < 2) {  // src/lanczos_cuda.c:324-327
+        printf("max_iter must be >= 2\n");
+        return EXIT_FAILURE;
+    }
+    if (nth_eig < 1) {  // src/lanczos.c:32-35
+        printf("nth_eig must be >= 1\n");
+        return EXIT_FAILURE;
+    }
+    memset(eigenvalues, 0, (size_t)nth_eig * sizeof(double));  // src/lanczos_cuda.c:359
+
+    const double t_start = now_sec();
+    double time_init = 0.0, time_diag = 0.0;
+    int status = EXIT_FAILURE;
+    const bool quiet = env_int("LANCZOS_HIP_QUIET", 0) != 0;
+    const int window = std::max(1, env_int("LANCZOS_HIP_WINDOW", 4));
+
+    lanczos_hip_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.struct_size = sizeof(opt);
+    opt.device = env_int("LANCZOS_HIP_DEVICE", -1);
+    opt.reorth = env_reorth();
+    opt.profile = env_int("LANCZOS_HIP_PROFILE", 1);
+    if (opt.reorth < 0) {
+        printf("LANCZOS_HIP_REORTH must be one of full|full2|mgs|cuda_compat|none\n");
+        return EXIT_FAILURE;
+    }
+    unsigned long long seed = 123456789ULL;  // the constant of src/lanczos_cuda.c:395
+    if (const char *s = getenv("LANCZOS_HIP_SEED"))
+        if (*s) seed = strtoull(s, NULL, 10);
+
+    lz::Engine *e = nullptr;
+    std::vector<hipEvent_t> done((size_t)window, nullptr);
+    std::vector<double> a((size_t)max_iter, 0.0), b((size_t)max_iter, 0.0), last((size_t)nth_eig, 0.0);
+    const int total = max_iter - 1;
+    int enq = 0;
+    bool reached_max = true;
+
+    if (lz::Engine::create(&e, (int64_t)mat->dimension, (int64_t)mat->length, mat->row_head_indexes,
+                           mat->column_index, mat->values, max_iter, &opt) != 0)
+        goto cleanup;
+    if (e->enable_host_history() != 0) goto cleanup;
+    {
+        std::vector<double> v0(mat->dimension);
+        lanczos_hip_gaussian_fill(seed, 0, (int64_t)mat->dimension, v0.data());
+        if (e->set_start(v0.data(), true, 1.0) != 0) goto cleanup;
+    }
+    for (auto &ev : done)
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            lz::fail("hipEventCreate failed");
+            goto cleanup;
+        }
+    time_init = now_sec() - t_start;
+    fprintf(stderr, "[INIT] name=total_wall sec=%.6f\n", time_init);
+    fprintf(stderr, "[INIT] name=spmv_kernel detail_ref=%s\n", e->spmv_name);
+
+    for (int k = 0; k < total; k++) {
+        while (enq < total && enq < k + window) {
+            if (e->enqueue_iteration() != 0) goto cleanup;
+            if (hipEventRecord(done[(size_t)(enq % window)], e->stream) != hipSuccess) {
+                lz::fail("hipEventRecord failed");
+                goto cleanup;
+            }
+            enq++;
+        }
+        if (hipEventSynchronize(done[(size_t)(k % window)]) != hipSuccess) {
+            lz::fail("hipEventSynchronize failed");
+            goto cleanup;
+        }
+        const double alpha = e->h_hist[2 * (size_t)k];
+        const double beta = e->h_hist[2 * (size_t)k + 1];
+        a[(size_t)k] = alpha;  // T(k,k), src/lanczos.c:113
+
+        int eval_count = k + 1;  // src/lanczos.c:105-108
+        if (eval_count > nth_eig) eval_count = nth_eig;
+        for (int i = 0; i < nth_eig; i++) last[(size_t)i] = eigenvalues[i];  // src/lanczos.c:114-116
+        const double td = now_sec();
+        if (lanczos_hip_tridiag_eigs(a.data(), b.data(), k + 1, nth_eig, eigenvalues) != 0) {
+            lz::fail("tridiagonal eigen-solve failed at step %d", k + 1);
+            goto cleanup;
+        }
+        time_diag += now_sec() - td;
+
+        bool all = true;  // src/lanczos.c:120-126
+        for (int i = 0; i < eval_count; i++) {
+            const double diff = eigenvalues[i] - last[(size_t)i];
+            if (diff * diff > threshold * threshold) all = false;
+        }
+        if (all) {  // src/lanczos.c:127-133
+            printf("converged ");
+            for (int i = 0; i < nth_eig; i++) printf("%.1E ", last[(size_t)i] - eigenvalues[i]);
+            printf("\n");
+            status = EXIT_SUCCESS;
+            reached_max = false;
+            break;
+        }
+        if (!quiet) {  // src/lanczos.c:134-138
+            printf("%d\t", k + 1);
+            for (int i = 0; i < nth_eig; i++) printf("%.7f\t", eigenvalues[i]);
+            printf("\n");
+        }
+        if (beta * beta < threshold * threshold * threshold * threshold) {  // src/lanczos.c:185-188
+            printf("%.7f beta converged\n", beta);
+            status = EXIT_SUCCESS;
+            reached_max = false;
+            break;
+        }
+        b[(size_t)k] = beta;  // T(k,k+1), src/lanczos.c:189-190
+    }
+    if (reached_max) {
+        status = EXIT_SUCCESS;
+        printf("Reached max iterations (%d)\n", max_iter);  // src/lanczos.c:193
+    }
+
+cleanup:
+    double t_spmv = 0.0, t_reorth = 0.0;
+    if (e) {
+        (void)hipStreamSynchronize(e->stream);
+        e->harvest_profile();
+        t_spmv = e->prof_ms[LANCZOS_HIP_K_SPMV] * 1e-3;
+        for (int c = LANCZOS_HIP_K_RECUR; c < LANCZOS_HIP_K_COUNT; c++) t_reorth += e->prof_ms[c] * 1e-3;
+    }
+    for (auto ev : done)
+        if (ev) (void)hipEventDestroy(ev);
+    delete e;
+    // the grammar of src/lanczos_cuda.c:782-786 (no T upload exists here, so no cudaMemcpy line)
+    fprintf(stderr, "[TOTAL] name=init detail_ref=INIT sec=%.6f\n", time_init);
+    fprintf(stderr, "[TOTAL] name=spmv sec=%.6f\n", t_spmv);
+    fprintf(stderr, "[TOTAL] name=diagonalization sec=%.6f\n", time_diag);
+    fprintf(stderr, "[TOTAL] name=reorthogonalization sec=%.6f\n", t_reorth);
+    fprintf(stderr, "[TOTAL] name=wall sec=%.6f\n", now_sec() - t_start);
+    return status;
+}

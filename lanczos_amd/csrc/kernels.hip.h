@@ -1,0 +1,398 @@
+// Device kernels of the Lanczos engine, written for gfx950 (CDNA4): 64-lane
+// wavefronts, 256-thread workgroups, 8 XCDs with private L2s.
+//
+// Every kernel here is bandwidth-bound fp64 streaming work; none is shaped as a
+// GEMM.  Reductions are two-stage and order-fixed (DPP inside a wavefront, LDS
+// across the 4 wavefronts of a workgroup, one partial per workgroup, a
+// single-workgroup finaliser), so results are bitwise reproducible run to run
+// for a fixed grid.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lz {
+
+constexpr int kBlock = 256;        // threads per workgroup (4 wavefronts)
+constexpr int kWavesPerBlock = 4;
+
+// ---------------------------------------------------------------------------
+// Wavefront reductions on DPP
+// ---------------------------------------------------------------------------
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_update_dpp(a.i[0], a.i[0], CTRL, 0xF, 0xF, false);
+    b.i[1] = __builtin_amdgcn_update_dpp(a.i[1], a.i[1], CTRL, 0xF, 0xF, false);
+    return b.d;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    union { double d; int i[2]; } a, b;
+    a.d = v;
+    b.i[0] = __builtin_amdgcn_readlane(a.i[0], lane);
+    b.i[1] = __builtin_amdgcn_readlane(a.i[1], lane);
+    return b.d;
+}
+
+// Sum over aligned groups of G lanes (G a power of two, 1..64); every lane of a
+// group ends up holding the group's sum.
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+    if constexpr (G >= 2) v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+    if constexpr (G >= 4) v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+    if constexpr (G >= 8) v += dpp_f64<0x141>(v);   // row_half_mirror
+    if constexpr (G >= 16) v += dpp_f64<0x140>(v);  // row_mirror
+    if constexpr (G >= 32) v += __shfl_xor(v, 16);
+    if constexpr (G >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+// Sum over the whole wavefront; the result is wave-uniform.
+__device__ __forceinline__ double wave_sum(double v) {
+    v = group_sum<16>(v);
+    return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// Sum over the workgroup; valid in every thread.  `red` is 4 doubles of LDS.
+__device__ __forceinline__ double block_sum(double v, double *red) {
+    const double s = wave_sum(v);
+    __syncthreads();  // protect `red` against a previous use
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---------------------------------------------------------------------------
+// SpMV, "vector" form: G = 2^g lanes cooperate on one row
+// ---------------------------------------------------------------------------
+//
+// y[row] = sum_j val[j] * x[col[j]]   (reference src/crs.c:155-178,
+//                                      src/lanczos_cuda.c:562-577)
+// fused with the per-workgroup partial of alpha = xdot . y
+// (src/lanczos.c:112, src/lanczos_cuda.c:580).
+//
+// Workgroups are dealt round-robin over the 8 XCDs, so workgroups b and b+8
+// share an L2.  Rows are cut into 8 contiguous ranges, one per b % 8, and the
+// workgroups of one range walk it side by side: the x entries a banded matrix
+// gathers stay inside one XCD's L2.
+template <int G, typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_vector(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+              const double *__restrict__ val, const double *__restrict__ x,
+              const double *__restrict__ xdot, double *__restrict__ y,
+              double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    constexpr int RPB = kBlock / G;  // rows per workgroup per pass
+    const int g_lane = threadIdx.x & (G - 1);
+    const int g_id = threadIdx.x / G;
+    const int64_t total = (n + RPB - 1) / RPB;
+    const int64_t per_xcd = (total + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > total) c_end = total;
+    double acc = 0.0;
+    for (int64_t c = xcd * per_xcd + slot; c < c_end; c += slots) {
+        const int64_t row = c * RPB + g_id;
+        double sum = 0.0;
+        if (row < n) {
+            const RP s = rp[row], e = rp[row + 1];
+            for (RP j = s + g_lane; j < e; j += G) sum += val[j] * x[col[j]];
+        }
+        sum = group_sum<G>(sum);
+        if (g_lane == 0 && row < n) {
+            y[row] = sum;
+            acc += sum * xdot[row];
+        }
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV, "stream" form: one wavefront per group of 64 rows
+// ---------------------------------------------------------------------------
+//
+// The 65 row offsets of a group are read once (coalesced) and kept in LDS.
+// The wavefront then streams the group's nnz span [rp[g0], rp[g0+64]) in tiles
+// of kTile entries with fully coalesced col/val loads, gathers x, and parks the
+// products in LDS; lane r finally sums the slice of each tile that belongs to
+// row g0 + r.  Lanes never idle on short rows and col/val traffic is contiguous
+// whatever the row lengths are.  A row longer than a tile is summed across
+// tiles by its lane.
+constexpr int kTile = 512;  // products per wavefront tile (4 KiB of LDS)
+
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_stream(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+              const double *__restrict__ val, const double *__restrict__ x,
+              const double *__restrict__ xdot, double *__restrict__ y,
+              double *__restrict__ partials) {
+    __shared__ double prod[kWavesPerBlock][kTile];
+    __shared__ RP offs[kWavesPerBlock][66];
+    __shared__ double red[kWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t groups = (n + 63) >> 6;
+    // one "chunk" = the 4 row groups handled by the 4 wavefronts of a workgroup
+    const int64_t total = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (total + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > total) c_end = total;
+    double acc = 0.0;
+    double *myprod = prod[wave];
+    RP *myoffs = offs[wave];
+    for (int64_t c = xcd * per_xcd + slot; c < c_end; c += slots) {
+        const int64_t g = c * kWavesPerBlock + wave;
+        if (g >= groups) continue;  // wave-uniform
+        const int64_t g0 = g << 6;
+        const int64_t row = g0 + lane;
+        // stage the row offsets of this group
+        {
+            int64_t r = row < n ? row : n;
+            myoffs[lane] = rp[r];
+            if (lane == 0) {
+                int64_t last = g0 + 64 < n ? g0 + 64 : n;
+                myoffs[64] = rp[last];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const RP span_lo = myoffs[0];
+        const RP span_hi = myoffs[64];
+        const RP my_lo = myoffs[lane];
+        const RP my_hi = (row < n) ? myoffs[lane + 1] : my_lo;
+        // note: for rows >= n offs[lane] == rp[n] so my_lo == my_hi == span_hi
+        double sum = 0.0;
+        for (RP t0 = span_lo; t0 < span_hi; t0 += kTile) {
+            const RP t1 = (t0 + kTile < span_hi) ? (RP)(t0 + kTile) : span_hi;
+#pragma unroll
+            for (int u = 0; u < kTile / 64; ++u) {
+                const RP j = t0 + u * 64 + lane;
+                if (j < t1) myprod[u * 64 + lane] = val[j] * x[col[j]];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const RP lo = my_lo > t0 ? my_lo : t0;
+            const RP hi = my_hi < t1 ? my_hi : t1;
+            for (RP j = lo; j < hi; ++j) sum += myprod[j - t0];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (row < n) {
+            y[row] = sum;
+            acc += sum * xdot[row];
+        }
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// ---------------------------------------------------------------------------
+// Small finaliser: out[0] = sum(partials[0..count)) in a fixed order
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_finalize(const double *__restrict__ partials, int count, double *__restrict__ out) {
+    __shared__ double red[kWavesPerBlock];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) s += partials[i];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
+// h[l] = sum_b hpart[l * stride + b], one workgroup per l
+__global__ void __launch_bounds__(kBlock)
+k_hreduce(const double *__restrict__ hpart, int stride, int count, double *__restrict__ h) {
+    __shared__ double red[kWavesPerBlock];
+    const double *p = hpart + (size_t)blockIdx.x * stride;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) s += p[i];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) h[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------
+// Three-term recurrence  w <- (w - beta * v_prev) - alpha * v_k
+// (src/lanczos.c:150-154; src/lanczos_cuda.c:671-677) fused with the partial
+// of w.w (src/lanczos.c:169-176).  Vectors are processed as double2; `n2` is
+// the number of double2 elements (vector padding is zero and stays zero).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kBlock)
+k_recur(double2 *__restrict__ w, const double2 *__restrict__ vk, const double2 *__restrict__ vprev,
+        int64_t n2, const double *__restrict__ alpha_p, const double *__restrict__ beta_p,
+        double *__restrict__ partials, double *__restrict__ alpha_hist, double *alpha_host) {
+    __shared__ double red[kWavesPerBlock];
+    const double alpha = alpha_p[0];
+    const double beta = vprev ? beta_p[0] : 0.0;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double acc = 0.0;
+    if (vprev) {
+#pragma unroll 4
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+            double2 a = w[i];
+            const double2 p = vprev[i], q = vk[i];
+            a.x = (a.x - beta * p.x) - alpha * q.x;
+            a.y = (a.y - beta * p.y) - alpha * q.y;
+            w[i] = a;
+            acc += a.x * a.x + a.y * a.y;
+        }
+    } else {
+#pragma unroll 4
+        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+            double2 a = w[i];
+            const double2 q = vk[i];
+            a.x = a.x - alpha * q.x;
+            a.y = a.y - alpha * q.y;
+            w[i] = a;
+            acc += a.x * a.x + a.y * a.y;
+        }
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = t;
+        if (blockIdx.x == 0) {
+            alpha_hist[0] = alpha;
+            if (alpha_host) alpha_host[0] = alpha;
+        }
+    }
+}
+
+// v_{k+1} = w / beta, beta = sqrt(norm2)   (src/lanczos.c:176-180)
+__global__ void __launch_bounds__(kBlock)
+k_scale(double2 *__restrict__ w, int64_t n2, const double *__restrict__ norm2_p,
+        double *__restrict__ beta_cur, double *__restrict__ beta_hist, double *beta_host) {
+    const double beta = sqrt(norm2_p[0]);
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+#pragma unroll 4
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        double2 a = w[i];
+        a.x /= beta;
+        a.y /= beta;
+        w[i] = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        beta_cur[0] = beta;
+        beta_hist[0] = beta;
+        if (beta_host) beta_host[0] = beta;
+    }
+}
+
+// v <- scale * v  (start-vector normalisation, src/lanczos.c:95-98)
+__global__ void __launch_bounds__(kBlock)
+k_scal_mul(double2 *__restrict__ v, int64_t n2, const double *__restrict__ norm2_p, double fixed) {
+    const double s = norm2_p ? 1.0 / sqrt(norm2_p[0]) : fixed;
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        double2 a = v[i];
+        a.x = s * a.x;
+        a.y = s * a.y;
+        v[i] = a;
+    }
+}
+
+// partials[b] = partial of a.b
+__global__ void __launch_bounds__(kBlock)
+k_dot(const double2 *__restrict__ a, const double2 *__restrict__ b, int64_t n2,
+      double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
+        const double2 p = a[i], q = b[i];
+        acc += p.x * q.x + p.y * q.y;
+    }
+    const double t = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+// ---------------------------------------------------------------------------
+// Reorthogonalisation against basis vectors l0..l1-1 as a blocked GEMV pair
+//   k_dots   : hpart[(l-l0) * hstride + block] = partial of V_l . w
+//   k_update : w -= sum_l h[l-l0] * V_l ; partials[block] = partial of w.w
+// (src/lanczos.c:156-167, src/lanczos_cuda.c:679-687).  A workgroup owns tiles
+// of kTileV2 consecutive double2 elements; the w tile stays in registers while
+// the basis streams past it once per kernel, so each kernel reads V exactly
+// once.  Every vector is padded with zeros to a whole number of tiles, so no
+// bounds checks are needed and the padding stays zero.
+// ---------------------------------------------------------------------------
+constexpr int kEPT2 = 4;                       // double2 per thread per tile
+constexpr int kTileV2 = kBlock * kEPT2;        // double2 per tile (2048 doubles)
+
+__global__ void __launch_bounds__(kBlock)
+k_dots(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, const double2 *__restrict__ w,
+       int64_t n2, double *__restrict__ hpart, int hstride) {
+    extern __shared__ double hs[];  // [4][nl]
+    const int nl = l1 - l0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < nl * kWavesPerBlock; j += kBlock) hs[j] = 0.0;
+    __syncthreads();
+    double *myhs = hs + wave * nl;
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 wt[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+#pragma unroll 2
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            double p = 0.0;
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                const double2 q = vl[u * kBlock];
+                p += q.x * wt[u].x + q.y * wt[u].y;
+            }
+            p = wave_sum(p);
+            if (lane == 0) myhs[l] += p;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nl; j += kBlock)
+        hpart[(size_t)j * hstride + blockIdx.x] = (hs[j] + hs[nl + j]) + (hs[2 * nl + j] + hs[3 * nl + j]);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_update(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *__restrict__ w,
+         int64_t n2, const double *__restrict__ h, double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    const int nl = l1 - l0;
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    double acc = 0.0;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 wt[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+#pragma unroll 2
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            const double c = h[l];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                const double2 q = vl[u * kBlock];
+                wt[u].x -= q.x * c;
+                wt[u].y -= q.y * c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) {
+            w[base + u * kBlock] = wt[u];
+            acc += wt[u].x * wt[u].x + wt[u].y * wt[u].y;
+        }
+    }
+    const double tsum = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
+}
+
+// 64-bit column indices -> 32-bit (matrix upload)
+__global__ void __launch_bounds__(kBlock)
+k_narrow_i64(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t count) {
+    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += stride)
+        out[i] = (int32_t)in[i];
+}
+
+}  // namespace lz

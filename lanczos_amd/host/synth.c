@@ -1,0 +1,187 @@
+/*
+ * Synthetic matrices for tests and benchmarks, generated straight into CRS
+ * (the reference ships no inputs: its .gitignore:6 keeps *.txt out of the tree).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../include/lanczos_host.h"
+
+void lanczos_free_crs(Mat_Crs *m) {
+    if (!m) return;
+    free(m->values);
+    free(m->column_index);
+    free(m->row_head_indexes);
+    memset(m, 0, sizeof *m);
+}
+
+static int alloc_crs(Mat_Crs *out, size_t n, size_t nnz) {
+    out->values = (double *)malloc(sizeof(double) * (nnz ? nnz : 1));
+    out->column_index = (int64_t *)malloc(sizeof(int64_t) * (nnz ? nnz : 1));
+    out->dimension = n;
+    out->length = nnz;
+    if (!out->values || !out->column_index) {
+        lanczos_free_crs(out);
+        return 1;
+    }
+    return 0;
+}
+
+int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out) {
+    if (!out || d < 1 || d > 3 || N < 1) return 1;
+    memset(out, 0, sizeof *out);
+    int64_t n = 1;
+    for (int i = 0; i < d; i++) {
+        if (n > INT32_MAX / N) return 1;
+        n *= N;
+    }
+    const int64_t stride[3] = {1, N, N * N};
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    if (!head) return 1;
+    out->row_head_indexes = head;
+    /* row lengths are known in closed form: 1 + number of in-range neighbours */
+    head[0] = 0;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        int cnt = 1;
+        int64_t rem = i;
+        for (int a = 0; a < d; a++) {
+            const int64_t c = rem % N;
+            rem /= N;
+            cnt += (c > 0) + (c < N - 1);
+        }
+        head[i + 1] = cnt;
+    }
+    for (int64_t i = 0; i < n; i++) head[i + 1] += head[i];
+    if (alloc_crs(out, (size_t)n, (size_t)head[n])) return 1;
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; i++) {
+        int64_t coord[3] = {0, 0, 0};
+        int64_t rem = i;
+        for (int a = 0; a < d; a++) {
+            coord[a] = rem % N;
+            rem /= N;
+        }
+        int64_t p = head[i];
+        for (int a = d - 1; a >= 0; a--) /* lower neighbours, ascending column */
+            if (coord[a] > 0) {
+                out->column_index[p] = i - stride[a];
+                out->values[p++] = -1.0;
+            }
+        out->column_index[p] = i;
+        out->values[p++] = 2.0 * d;
+        for (int a = 0; a < d; a++)
+            if (coord[a] < N - 1) {
+                out->column_index[p] = i + stride[a];
+                out->values[p++] = -1.0;
+            }
+    }
+    return 0;
+}
+
+static inline uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+typedef struct {
+    int32_t r, c;
+    double v;
+} ent_t;
+
+int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Crs *out) {
+    if (!out || n < 1 || n > INT32_MAX || per_row < 0) return 1;
+    memset(out, 0, sizeof *out);
+    const uint64_t key = mix64(seed);
+    const size_t draws = (size_t)n * (size_t)per_row;
+    /* pass 1: count both orientations of every off-diagonal draw */
+    int64_t *cnt = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+    if (!cnt) return 1;
+    for (int64_t i = 0; i < n; i++)
+        for (int t = 0; t < per_row; t++) {
+            const int64_t j = (int64_t)(mix64(key ^ (uint64_t)(2 * (i * per_row + t))) % (uint64_t)n);
+            if (j == i) continue;
+            cnt[i + 1]++;
+            cnt[j + 1]++;
+        }
+    for (int64_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
+    const size_t tot = (size_t)cnt[n];
+    ent_t *buf = (ent_t *)malloc(sizeof(ent_t) * (tot ? tot : 1));
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    if (!buf || !cur) {
+        free(cnt); free(buf); free(cur);
+        return 1;
+    }
+    memcpy(cur, cnt, sizeof(int64_t) * (size_t)n);
+    for (int64_t i = 0; i < n; i++)
+        for (int t = 0; t < per_row; t++) {
+            const uint64_t id = (uint64_t)(i * per_row + t);
+            const int64_t j = (int64_t)(mix64(key ^ (2 * id)) % (uint64_t)n);
+            if (j == i) continue;
+            const double v = (double)(mix64(key ^ (2 * id + 1)) >> 11) / 4503599627370496.0 - 1.0;
+            ent_t a = {(int32_t)i, (int32_t)j, v}, b = {(int32_t)j, (int32_t)i, v};
+            buf[cur[i]++] = a;
+            buf[cur[j]++] = b;
+        }
+    (void)draws;
+    /* per row: sort by column (insertion sort, rows are short), drop repeats of a
+     * column keeping the first (both orientations see the same winner only if
+     * the order is orientation independent, so order ties by value bits) */
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    if (!head) { free(cnt); free(buf); free(cur); return 1; }
+    head[0] = 0;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; i++) {
+        ent_t *row = buf + cnt[i];
+        const int64_t m = cnt[i + 1] - cnt[i];
+        for (int64_t a = 1; a < m; a++) {
+            ent_t x = row[a];
+            int64_t b = a - 1;
+            while (b >= 0 && (row[b].c > x.c || (row[b].c == x.c && row[b].v > x.v))) {
+                row[b + 1] = row[b];
+                b--;
+            }
+            row[b + 1] = x;
+        }
+        int64_t uniq = 0;
+        for (int64_t a = 0; a < m; a++)
+            if (a == 0 || row[a].c != row[a - 1].c) uniq++;
+        head[i + 1] = uniq + 1; /* + diagonal */
+    }
+    for (int64_t i = 0; i < n; i++) head[i + 1] += head[i];
+    out->row_head_indexes = head;
+    if (alloc_crs(out, (size_t)n, (size_t)head[n])) { free(cnt); free(buf); free(cur); return 1; }
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int64_t i = 0; i < n; i++) {
+        const ent_t *row = buf + cnt[i];
+        const int64_t m = cnt[i + 1] - cnt[i];
+        double absum = 0.0;
+        for (int64_t a = 0; a < m; a++)
+            if (a == 0 || row[a].c != row[a - 1].c) absum += fabs(row[a].v);
+        int64_t p = head[i];
+        int placed = 0;
+        for (int64_t a = 0; a < m; a++) {
+            if (a > 0 && row[a].c == row[a - 1].c) continue;
+            if (!placed && row[a].c > i) {
+                out->column_index[p] = i;
+                out->values[p++] = 1.0 + absum;
+                placed = 1;
+            }
+            out->column_index[p] = row[a].c;
+            out->values[p++] = row[a].v;
+        }
+        if (!placed) {
+            out->column_index[p] = i;
+            out->values[p++] = 1.0 + absum;
+        }
+    }
+    free(cnt);
+    free(buf);
+    free(cur);
+    return 0;
+}

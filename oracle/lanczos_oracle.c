@@ -1,0 +1,508 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- CPU restatement of the reference algorithm.
+ *
+ * Nothing under oracle/ is product code.  Only tests/, the smoke check and the
+ * cpu_baseline leg of bench.py may load this library, and only as the checker
+ * that the HIP path is compared against.
+ *
+ * Each function names the reference lines whose behaviour it restates
+ * (paths relative to the reference tree).  The arithmetic order of the
+ * reference is kept where it decides the result (the order of the three-term
+ * recurrence, sequential Gram-Schmidt in ascending basis index, division by
+ * beta, alpha taken before orthogonalisation).
+ *
+ * Pinning: the COO->CRS build, the triplet parser and both matvecs are checked
+ * byte-for-byte against the reference's own crs.c / coo.c compiled as they lie
+ * (oracle/_ref, see oracle/Makefile).  The Lanczos loop is pinned by the
+ * reference's recorded Ritz values for fixed start vectors (tests/golden/
+ * reference_known_answers.json) and by closed-form Laplacian spectra.  The dense
+ * eigen-solve of the reference is Intel MKL LAPACKE_dsyevr_work (third party,
+ * version unpinned by the reference's Makefile:4, not vendored); it is restated
+ * here as an implicit QL iteration and checked against LAPACK dsyevr/dstebz.
+ */
+#include <ctype.h>
+#include <float.h>
+#include <limits.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int row;
+    int col;
+    double val;
+} orc_coo_t; /* same layout as Coo, src/coo.h:3-7 */
+
+static double orc_now(void) {
+#ifdef _OPENMP
+    return omp_get_wtime();
+#else
+    return 0.0;
+#endif
+}
+
+/* Start vector of the recorded known answers: xorshift64 from
+ * 0x9E3779B97F4A7C15, r[i] = (s >> 11) / 2^53 - 0.5. */
+void orc_xorshift_start(uint64_t n, double *out) {
+    uint64_t s = 0x9E3779B97F4A7C15ULL;
+    for (uint64_t i = 0; i < n; i++) {
+        s ^= s << 13;
+        s ^= s >> 7;
+        s ^= s << 17;
+        out[i] = (double)(s >> 11) / 9007199254740992.0 - 0.5;
+    }
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* ------------------------------------------------------------------------- */
+/* Triplet text ingest                                                        */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * One "row col value" line -> 0-based entry.  Restates src/coo.c:11-40:
+ * leading whitespace skipped before each field, strtol base 10 for the two
+ * indices, "%lg" for the value, 1-based -> 0-based.  Returns 0 on success,
+ * 1 if the first index is missing, 2 if the second is (the reference exits
+ * the process in both cases, src/coo.c:19-22, 27-30).  A missing value field
+ * leaves *out_val untouched, as the reference leaves it unset (src/coo.c:34).
+ */
+int orc_parse_line(const char *line, int *out_row, int *out_col, double *out_val) {
+    const char *p = line;
+    char *end = NULL;
+    while (isspace((unsigned char)*p)) p++;
+    long r = strtol(p, &end, 10);
+    if (end == p) return 1;
+    p = end;
+    while (isspace((unsigned char)*p)) p++;
+    long c = strtol(p, &end, 10);
+    if (end == p) return 2;
+    p = end;
+    while (isspace((unsigned char)*p)) p++;
+    double v;
+    if (sscanf(p, "%lg", &v) == 1) *out_val = v;
+    *out_row = (int)r - 1;
+    *out_col = (int)c - 1;
+    return 0;
+}
+
+/*
+ * Whole-file ingest.  Restates src/coo.c:101-269: lines are split on '\n',
+ * only zero-length lines are skipped (src/coo.c:149, 229), a last line without
+ * a newline still counts (src/coo.c:167-169, 250-255), and the dimension is
+ * 1 + the running maximum of every index, where the maximum is taken in
+ * size_t so a negative index wraps (src/coo.c:231-232 with util.h:4).
+ *
+ * Two-call protocol: entries == NULL counts lines; otherwise fills up to
+ * `capacity` entries.  Returns the number of entries, or -1 on I/O error,
+ * -2 on a malformed line.
+ */
+long orc_read_triplets(const char *path, orc_coo_t *entries, long capacity, uint64_t *out_dim) {
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    size_t cap = 1 << 16, len = 0;
+    char *buf = (char *)malloc(cap);
+    long count = 0;
+    size_t dim = 0;
+    int ch;
+    int at_eof = 0;
+    while (!at_eof) {
+        ch = fgetc(fp);
+        if (ch == EOF) at_eof = 1;
+        if (ch == '\n' || at_eof) {
+            if (len > 0) {
+                buf[len] = '\0';
+                if (entries) {
+                    if (count >= capacity) break;
+                    orc_coo_t e;
+                    e.val = 0.0;
+                    if (orc_parse_line(buf, &e.row, &e.col, &e.val) != 0) {
+                        free(buf);
+                        fclose(fp);
+                        return -2;
+                    }
+                    entries[count] = e;
+                    size_t a = (size_t)e.row, b = (size_t)e.col;
+                    if (!(dim >= a)) dim = a;
+                    if (!(dim >= b)) dim = b;
+                }
+                count++;
+            }
+            len = 0;
+        } else {
+            if (len + 2 > cap) {
+                cap *= 2;
+                buf = (char *)realloc(buf, cap);
+            }
+            buf[len++] = (char)ch;
+        }
+    }
+    free(buf);
+    fclose(fp);
+    if (out_dim) *out_dim = (uint64_t)(dim + 1);
+    return count;
+}
+
+/* ------------------------------------------------------------------------- */
+/* COO -> CRS                                                                 */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * Stable counting sort of triplets into CRS.  Restates src/crs.c:8-153:
+ * optional exchange of the two indices (src/crs.c:63-67), range check
+ * (src/crs.c:68-77), per-row counts, exclusive prefix sum into
+ * row_head[dim+1] (src/crs.c:82-94), scatter in input order so entries of one
+ * row keep file order and duplicates stay separate (src/crs.c:118-140).
+ * Outputs are caller-allocated: values[len], column_index[len] (int64),
+ * row_head[dim+1] (int64).  Returns 0, or 1 + index of the first
+ * out-of-range entry.
+ */
+long orc_coo_to_crs(const orc_coo_t *coo, uint64_t len, uint64_t dim, int swap,
+                    double *values, int64_t *column_index, int64_t *row_head) {
+    for (uint64_t r = 0; r <= dim; r++) row_head[r] = 0;
+    for (uint64_t i = 0; i < len; i++) {
+        int r = swap ? coo[i].col : coo[i].row;
+        int c = swap ? coo[i].row : coo[i].col;
+        if (r < 0 || c < 0 || (uint64_t)r >= dim || (uint64_t)c >= dim) return (long)i + 1;
+        row_head[(uint64_t)r + 1]++;
+    }
+    for (uint64_t r = 0; r < dim; r++) row_head[r + 1] += row_head[r];
+    int64_t *cursor = (int64_t *)malloc(sizeof(int64_t) * (dim ? dim : 1));
+    memcpy(cursor, row_head, sizeof(int64_t) * dim);
+    for (uint64_t i = 0; i < len; i++) {
+        int r = swap ? coo[i].col : coo[i].row;
+        int c = swap ? coo[i].row : coo[i].col;
+        int64_t pos = cursor[r]++;
+        values[pos] = coo[i].val;
+        column_index[pos] = (int64_t)c;
+    }
+    free(cursor);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Matvecs and dot                                                            */
+/* ------------------------------------------------------------------------- */
+
+/*
+ * y = A x for CRS.  Restates src/crs.c:155-178: one sum per row over
+ * row_head[i] .. row_head[i+1], result overwrites y[i].  The reference lets
+ * the compiler reorder the row sum (omp simd reduction, src/crs.c:172); this
+ * restatement sums left to right, which is one of the admissible orders.
+ */
+void orc_matvec_crs(uint64_t dim, const int64_t *row_head, const int64_t *column_index,
+                    const double *values, const double *x, double *y) {
+#pragma omp parallel for schedule(guided) if (dim >= 1024)
+    for (uint64_t i = 0; i < dim; i++) {
+        double s = 0.0;
+        for (int64_t j = row_head[i]; j < row_head[i + 1]; j++) s += values[j] * x[column_index[j]];
+        y[i] = s;
+    }
+}
+
+/* y = A x for triplets.  Restates src/coo.c:271-283: zero y, then scatter-add
+ * in entry order. */
+void orc_matvec_coo(const orc_coo_t *coo, uint64_t len, uint64_t dim, const double *x, double *y) {
+    for (uint64_t i = 0; i < dim; i++) y[i] = 0.0;
+    for (uint64_t i = 0; i < len; i++) y[coo[i].row] += coo[i].val * x[coo[i].col];
+}
+
+/* Restates src/util.c:58-65 (serial sum, left to right being one admissible
+ * order of its simd reduction). */
+double orc_dot(const double *a, const double *b, int n) {
+    double s = 0.0;
+    for (int i = 0; i < n; i++) s += a[i] * b[i];
+    return s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* Lowest eigenvalues of the leading n x n block of T                         */
+/* ------------------------------------------------------------------------- */
+
+static int cmp_double(const void *a, const void *b) {
+    double x = *(const double *)a, y = *(const double *)b;
+    return (x > y) - (x < y);
+}
+
+/*
+ * All eigenvalues of a symmetric tridiagonal matrix by the implicit QL
+ * iteration with Wilkinson shift (the published EISPACK tql1 / LAPACK dsterf
+ * family).  d[n] diagonal (overwritten with eigenvalues, unsorted),
+ * e[n] sub-diagonal in e[0..n-2] (destroyed).  Returns 0 on success.
+ */
+static int ql_implicit(double *d, double *e, int n) {
+    if (n <= 1) return 0;
+    e[n - 1] = 0.0;
+    for (int l = 0; l < n; l++) {
+        int iter = 0;
+        int m;
+        do {
+            for (m = l; m < n - 1; m++) {
+                double dd = fabs(d[m]) + fabs(d[m + 1]);
+                if (fabs(e[m]) <= DBL_EPSILON * dd) break;
+            }
+            if (m != l) {
+                if (iter++ == 200) return 1;
+                double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
+                double r = hypot(g, 1.0);
+                g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? fabs(r) : -fabs(r)));
+                double s = 1.0, c = 1.0, p = 0.0;
+                int i;
+                for (i = m - 1; i >= l; i--) {
+                    double f = s * e[i];
+                    double b = c * e[i];
+                    r = hypot(f, g);
+                    e[i + 1] = r;
+                    if (r == 0.0) {
+                        d[i + 1] -= p;
+                        e[m] = 0.0;
+                        break;
+                    }
+                    s = f / r;
+                    c = g / r;
+                    g = d[i + 1] - p;
+                    r = (d[i] - g) * s + 2.0 * c * b;
+                    p = s * r;
+                    d[i + 1] = g + p;
+                    g = c * r - b;
+                }
+                if (r == 0.0 && i >= l) continue;
+                d[l] -= p;
+                e[l] = g;
+                e[m] = 0.0;
+            }
+        } while (m != l);
+    }
+    return 0;
+}
+
+/*
+ * Restates diagonalize_double_partial, src/util.c:118-272: take the leading
+ * n x n block of the column-major matrix `t` (leading dimension ld), read its
+ * upper triangle only (src/util.c:189, 242 pass 'U'), return the lowest
+ * iu = min(nth, n) eigenvalues ascending (range 'I', il = 1, src/util.c:195-196,
+ * 248-249) and zero eig[iu .. nth) (src/util.c:269-271).
+ *
+ * The Lanczos loop only ever stores a tridiagonal matrix there
+ * (src/lanczos.c:113, 189-190), so the diagonal and first super-diagonal of
+ * the upper triangle are the whole input; any other non-zero in the upper
+ * triangle is reported with return code 2.
+ */
+int orc_diag_partial(const double *t, int ld, double *eig, int n, int nth) {
+    if (n <= 0 || ld < n || nth < 1) return 3;
+    double *d = (double *)malloc(sizeof(double) * (size_t)n * 2);
+    double *e = d + n;
+    for (int j = 0; j < n; j++) {
+        d[j] = t[(size_t)j * ld + j];
+        e[j] = 0.0;
+        for (int i = 0; i < j; i++) {
+            double u = t[(size_t)j * ld + i];
+            if (i == j - 1) e[i] = u;
+            else if (u != 0.0) { free(d); return 2; }
+        }
+    }
+    int rc = ql_implicit(d, e, n);
+    if (rc) { free(d); return 1; }
+    qsort(d, (size_t)n, sizeof(double), cmp_double);
+    int iu = nth < n ? nth : n;
+    for (int i = 0; i < iu; i++) eig[i] = d[i];
+    for (int i = iu; i < nth; i++) eig[i] = 0.0;
+    free(d);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* The Lanczos loop                                                           */
+/* ------------------------------------------------------------------------- */
+
+typedef void orc_matvec_fn(const void *mat, const double *x, double *y);
+
+typedef struct {
+    uint64_t dim;
+    const int64_t *row_head;
+    const int64_t *column_index;
+    const double *values;
+} orc_crs_view;
+
+static void matvec_crs_thunk(const void *m, const double *x, double *y) {
+    const orc_crs_view *a = (const orc_crs_view *)m;
+    orc_matvec_crs(a->dim, a->row_head, a->column_index, a->values, x, y);
+}
+
+typedef struct {
+    const orc_coo_t *coo;
+    uint64_t len, dim;
+} orc_coo_view;
+
+static void matvec_coo_thunk(const void *m, const double *x, double *y) {
+    const orc_coo_view *a = (const orc_coo_view *)m;
+    orc_matvec_coo(a->coo, a->len, a->dim, x, y);
+}
+
+/*
+ * Restates lanczos(), src/lanczos.c:10-212, with the start vector injected
+ * (the reference draws it from MKL dlarnv seeded by time(NULL),
+ * src/util.c:48-56, so no two reference runs share one).
+ *
+ *   v0          start vector, length dim; copied, then normalised by
+ *               multiplying with 1/sqrt(v0.v0) (src/lanczos.c:95-98)
+ *   reorth_mode 0 = the CPU reference: Gram-Schmidt against every l < k
+ *                   (src/lanczos.c:156-167)
+ *               1 = the CUDA reference's range j < k-2
+ *                   (src/lanczos_cuda.c:679-687)
+ *               2 = none
+ *   alpha_out   [max_iter-1] alpha_k as stored in T(k,k) (src/lanczos.c:113)
+ *   beta_out    [max_iter-1] beta_k  (src/lanczos.c:176, 189-190)
+ *   ritz_hist   optional [(max_iter-1) * nth] eigenvalues after each step
+ *   timing      optional [4]: init, spmv, diagonalization, reorthogonalization
+ *               seconds, the split of src/lanczos.c:208-211
+ *   verbose     non-zero prints the reference's stdout lines
+ *               (src/lanczos.c:128-138, 186, 193)
+ *
+ * Returns the number of completed iterations k for which alpha_k was stored;
+ * *exit_kind = 0 max-iter (src/lanczos.c:193), 1 Ritz convergence
+ * (src/lanczos.c:127-133), 2 beta convergence (src/lanczos.c:185-188),
+ * negative for bad arguments / allocation failure (the reference exits the
+ * process there, src/lanczos.c:28-56).
+ */
+static int lanczos_core(const void *mat, orc_matvec_fn *matvec, uint64_t dim, const double *v0,
+                        double *eigenvalues, int nth, int max_iter, double threshold,
+                        int reorth_mode, double *alpha_out, double *beta_out, double *ritz_hist,
+                        double *timing, int verbose, int *exit_kind) {
+    *exit_kind = -1;
+    if (!mat || !matvec || !eigenvalues || !v0) return 0;
+    if (max_iter < 2 || nth < 1 || dim == 0 || dim > (uint64_t)INT_MAX) return 0;
+    const int ld = max_iter;
+    const int n = (int)dim;
+    double t_init = 0, t_mv = 0, t_diag = 0, t_re = 0;
+    double t0 = orc_now();
+    double *v = (double *)calloc((size_t)max_iter * dim, sizeof(double));
+    double *tmat = (double *)calloc((size_t)ld * ld, sizeof(double));
+    double *last = (double *)calloc((size_t)nth, sizeof(double));
+    if (!v || !tmat || !last) { free(v); free(tmat); free(last); *exit_kind = -2; return 0; }
+#define VEC(k) (v + (size_t)(k) * dim)
+#define TM(i, j) tmat[(size_t)(j) * ld + (i)]
+    for (int i = 0; i < nth; i++) eigenvalues[i] = 0.0;
+    memcpy(VEC(0), v0, sizeof(double) * dim);
+    {
+        double nrm = sqrt(orc_dot(VEC(0), VEC(0), n));
+        for (int i = 0; i < n; i++) VEC(0)[i] = (1.0 / nrm) * VEC(0)[i];
+    }
+    t_init = orc_now() - t0;
+
+    double alpha = 0.0, beta = 0.0;
+    int done = 0;
+    *exit_kind = 0;
+    for (int k = 0; k < max_iter - 1; k++) {
+        int eval_count = (k + 1 > nth) ? nth : k + 1;
+        double *vk = VEC(k), *w = VEC(k + 1);
+        double ts = orc_now();
+        matvec(mat, vk, w);
+        t_mv += orc_now() - ts;
+        alpha = orc_dot(vk, w, n);
+        TM(k, k) = alpha;
+        alpha_out[k] = alpha;
+        for (int i = 0; i < nth; i++) last[i] = eigenvalues[i];
+        ts = orc_now();
+        if (orc_diag_partial(tmat, ld, eigenvalues, k + 1, nth) != 0) { *exit_kind = -3; break; }
+        t_diag += orc_now() - ts;
+        if (ritz_hist) memcpy(ritz_hist + (size_t)k * nth, eigenvalues, sizeof(double) * nth);
+        done = k + 1;
+        int all = 1;
+        for (int i = 0; i < eval_count; i++) {
+            double diff = eigenvalues[i] - last[i];
+            if (diff * diff > threshold * threshold) all = 0;
+        }
+        if (all) {
+            if (verbose) {
+                printf("converged ");
+                for (int i = 0; i < nth; i++) printf("%.1E ", last[i] - eigenvalues[i]);
+                printf("\n");
+            }
+            *exit_kind = 1;
+            break;
+        }
+        if (verbose) {
+            printf("%d\t", k + 1);
+            for (int i = 0; i < nth; i++) printf("%.7f\t", eigenvalues[i]);
+            printf("\n");
+        }
+
+        ts = orc_now();
+        const double *vp = (k == 0) ? NULL : VEC(k - 1);
+        int l_end = (reorth_mode == 0) ? k : (reorth_mode == 1 ? k - 2 : 0);
+        double coeff = 0.0, beta_sq = 0.0;
+#pragma omp parallel
+        {
+#pragma omp for
+            for (int i = 0; i < n; i++) {
+                double prev = vp ? vp[i] : 0.0;
+                w[i] = w[i] - beta * prev - alpha * vk[i];
+            }
+            for (int l = 0; l < l_end; l++) {
+                const double *vl = VEC(l);
+#pragma omp single
+                coeff = 0.0;
+#pragma omp for reduction(+ : coeff)
+                for (int i = 0; i < n; i++) coeff += vl[i] * w[i];
+#pragma omp for
+                for (int i = 0; i < n; i++) w[i] -= vl[i] * coeff;
+            }
+#pragma omp single
+            beta_sq = 0.0;
+#pragma omp for reduction(+ : beta_sq)
+            for (int i = 0; i < n; i++) beta_sq += w[i] * w[i];
+#pragma omp single
+            beta = sqrt(beta_sq);
+#pragma omp for
+            for (int i = 0; i < n; i++) w[i] /= beta;
+        }
+        t_re += orc_now() - ts;
+        beta_out[k] = beta;
+        if (beta * beta < threshold * threshold * threshold * threshold) {
+            if (verbose) printf("%.7f beta converged\n", beta);
+            *exit_kind = 2;
+            break;
+        }
+        TM(k, k + 1) = beta;
+        TM(k + 1, k) = beta;
+    }
+    if (*exit_kind == 0 && verbose) printf("Reached max iterations (%d)\n", max_iter);
+#undef VEC
+#undef TM
+    free(last);
+    free(tmat);
+    free(v);
+    if (timing) { timing[0] = t_init; timing[1] = t_mv; timing[2] = t_diag; timing[3] = t_re; }
+    return done;
+}
+
+int orc_lanczos_crs(uint64_t dim, const int64_t *row_head, const int64_t *column_index,
+                    const double *values, const double *v0, double *eigenvalues, int nth,
+                    int max_iter, double threshold, int reorth_mode, double *alpha_out,
+                    double *beta_out, double *ritz_hist, double *timing, int verbose,
+                    int *exit_kind) {
+    orc_crs_view a = {dim, row_head, column_index, values};
+    return lanczos_core(&a, matvec_crs_thunk, dim, v0, eigenvalues, nth, max_iter, threshold,
+                        reorth_mode, alpha_out, beta_out, ritz_hist, timing, verbose, exit_kind);
+}
+
+int orc_lanczos_coo(const orc_coo_t *coo, uint64_t len, uint64_t dim, const double *v0,
+                    double *eigenvalues, int nth, int max_iter, double threshold, int reorth_mode,
+                    double *alpha_out, double *beta_out, double *ritz_hist, double *timing,
+                    int verbose, int *exit_kind) {
+    orc_coo_view a = {coo, len, dim};
+    return lanczos_core(&a, matvec_coo_thunk, dim, v0, eigenvalues, nth, max_iter, threshold,
+                        reorth_mode, alpha_out, beta_out, ritz_hist, timing, verbose, exit_kind);
+}
