@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Benchmark of the Lanczos hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload lap256] [--reorth full]
+
+One "step" is one Lanczos iteration (SpMV, alpha, three-term recurrence,
+reorthogonalisation against the resident basis, beta, normalisation) of the
+workload; the timed region is a fresh run of exactly K iterations from the
+start vector with the matrix, the basis and every scalar resident in HBM.
+Rank 0 prints one JSON line.  For N > 1 the matrix is row-partitioned over the
+ranks (strong scaling, one process per GPU, collectives through
+torch.distributed / RCCL).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E peak, GB/s
+
+WORKLOADS = {
+    # name: (dimension d, grid N)
+    "lap256": (3, 256),   # 3-D 7-point Laplacian 256^3: n = 16 777 216, nnz = 117 047 296
+    "lap512": (3, 512),   # 512^3: n = 134 217 728, nnz = 937 951 232
+    "lap128": (3, 128),
+    "lap64": (3, 64),
+}
+
+
+def algorithmic_bytes(n: int, nnz: int) -> dict:
+    wp = 4 if nnz < 2**31 else 8
+    b_spmv = 12 * nnz + wp * (n + 1) + 16 * n
+    return {"spmv": b_spmv, "vec": 64 * n, "iter": b_spmv + 64 * n}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="lap256", choices=sorted(WORKLOADS))
+    ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none"])
+    ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=12)
+    return ap.parse_args()
+
+
+def cpu_baseline(a, v0, steps: int) -> dict:
+    """Time the CPU restatement of the reference loop (oracle/) on a bounded
+    sample: the first `steps` iterations of the same matrix and start vector,
+    full reorthogonalisation, all host threads OpenMP gives it."""
+    import oracle
+    t0 = time.perf_counter()
+    r = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0, "full")
+    wall = time.perf_counter() - t0
+    loop = r.timing["spmv"] + r.timing["diagonalization"] + r.timing["reorthogonalization"]
+    return {
+        "value": steps / loop,
+        "unit": "iters/s",
+        "cores": oracle.num_threads(),
+        "kind": "port",
+        "sample": f"first {steps} iterations (k < {steps}) of the same matrix and start vector, "
+                  f"full reorthogonalisation, threshold 0; loop {loop:.2f} s of {wall:.2f} s wall "
+                  f"(spmv {r.timing['spmv']:.2f} s, reorth {r.timing['reorthogonalization']:.2f} s)",
+        "ritz": [float(x) for x in r.eigenvalues],
+        "alpha": [float(x) for x in r.alpha[:steps]],
+        "beta": [float(x) for x in r.beta[:steps]],
+    }
+
+
+def roofline_from_profile(prof: dict) -> dict:
+    """Dominant kernel class by accumulated HIP-event time."""
+    name = max(prof, key=lambda k: prof[k]["ms"])
+    p = prof[name]
+    achieved = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+    return {
+        "bound": "hbm",
+        "kernel": name,
+        "achieved": achieved,
+        "peak": HBM_PEAK_GBPS,
+        "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBPS,
+        "traffic": None,
+        "launches": p["launches"],
+        "avg_launch_ms": p["ms"] / max(p["launches"], 1),
+        "algorithmic_bytes_per_launch": p["bytes"] / max(p["launches"], 1),
+    }
+
+
+def single_gpu(args) -> dict:
+    import torch
+    import lanczos_amd as la
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (torch.cuda.is_available() is False)")
+    d, N = WORKLOADS[args.workload]
+    t0 = time.perf_counter()
+    a = la.synth_laplacian(d, N)
+    n, nnz = a.dimension, a.length
+    v0 = la.gaussian_fill(123456789, 0, n)
+    t_gen = time.perf_counter() - t0
+    bytes_ = algorithmic_bytes(n, nnz)
+    K, W = args.steps, args.warmup
+
+    t0 = time.perf_counter()
+    eng = la.Engine(a, max(K, W) + 1, reorth=args.reorth, spmv=args.spmv, profile=True)
+    t_upload = time.perf_counter() - t0
+
+    # warm-up: W iterations of a throw-away run
+    eng.set_start(v0)
+    if W > 0:
+        eng.run(W)
+    eng.set_start(v0)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    alpha, beta = eng.run(K)          # enqueues K iterations, then drains the stream
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.profile()
+    ritz = la.ritz_values(alpha, beta, K, 4)
+
+    # the SpMV + vector step on its own (no reorthogonalisation): the part of the
+    # iteration whose bytes do not grow with k
+    sv = None
+    eng.close()
+    eng2 = la.Engine(a, 4, reorth="none", spmv=args.spmv, profile=True)
+    eng2.set_start(v0)
+    eng2.run(5)
+    eng2.profile_reset()
+    torch.cuda.synchronize()
+    S = 100
+    t1 = time.perf_counter()
+    eng2.run(S)
+    torch.cuda.synchronize()
+    dt2 = time.perf_counter() - t1
+    p2 = eng2.profile()
+    spmv_name = eng2.spmv_name
+    eng2.close()
+    spmv_gbps = p2["spmv"]["bytes"] / (p2["spmv"]["ms"] * 1e-3) / 1e9
+    sv = {
+        "iters_per_s": S / dt2,
+        "ms_per_iter": dt2 / S * 1e3,
+        "algorithmic_bytes_per_iter": bytes_["iter"],
+        "achieved_GBps": bytes_["iter"] * S / dt2 / 1e9,
+        "frac_of_hbm_peak": bytes_["iter"] * S / dt2 / 1e9 / HBM_PEAK_GBPS,
+        "spmv_kernel": spmv_name,
+        "spmv_avg_ms": p2["spmv"]["ms"] / S,
+        "spmv_GBps": spmv_gbps,
+        "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
+        "kernel_ms_per_iter": {k: v["ms"] / S for k, v in p2.items()},
+    }
+
+    out = {
+        "metric": "Lanczos iters/sec",
+        "value": K / dt,
+        "unit": "iters/s",
+        "n_gpus": 1,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": dt / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), {K} Lanczos steps from a fixed "
+                        f"N(0,1) start vector, reorth={args.reorth}, basis resident in HBM",
+            "reorth": args.reorth,
+            "spmv_kernel": spmv_name,
+            "parallelism": "1 GPU",
+        },
+        "roofline": roofline_from_profile(prof),
+        "spmv_hbm_GBps": spmv_gbps,
+        "spmv_vector_step": sv,
+        "kernel_ms_total": {k: v["ms"] for k, v in prof.items()},
+        "ritz_lowest4": [float(x) for x in ritz],
+        "setup_s": {"generate": t_gen, "upload": t_upload},
+    }
+    if not args.no_cpu_baseline:
+        cb = cpu_baseline(a, v0, args.cpu_steps)
+        s = args.cpu_steps
+        # the same sample on the GPU, and the agreement of the two alpha/beta sequences
+        cb["gpu_same_sample_rel_err"] = {
+            "alpha": float(np.max(np.abs(alpha[:s] - np.array(cb["alpha"])) / np.abs(np.array(cb["alpha"])))),
+            "beta": float(np.max(np.abs(beta[:s] - np.array(cb["beta"])) / np.abs(np.array(cb["beta"])))),
+        }
+        del cb["alpha"], cb["beta"], cb["ritz"]
+        out["cpu_baseline"] = cb
+    return out
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 or world > 1:
+        from lanczos_amd.dist import bench_distributed
+        out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return
+    print(json.dumps(single_gpu(args)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -108,7 +108,9 @@ enum {
 enum {
     LANCZOS_HIP_SPMV_AUTO = 0,
     LANCZOS_HIP_SPMV_VECTOR = 1, /* 2^g lanes per row, g chosen from mean row length */
-    LANCZOS_HIP_SPMV_STREAM = 2  /* one wavefront per group of rows, nnz streamed through LDS */
+    LANCZOS_HIP_SPMV_STREAM = 2, /* one wavefront per group of 64 rows, nnz streamed through LDS */
+    LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups (the default) */
+    LANCZOS_HIP_SPMV_PIPE_NT = 4 /* pipe form with non-temporal col/val loads */
 };
 
 /* Kernel classes for lanczos_hip_profile(). */

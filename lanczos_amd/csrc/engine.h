@@ -48,7 +48,8 @@ struct Engine {
     bool own_stream = false;
     // SpMV variant
     int spmv_kind = 0;
-    int group = 8;
+    int group = 8;   // lanes per row of the vector kernel
+    int log2r = 6;   // log2(rows per wavefront group) of the pipe kernel
     char spmv_name[32] = "";
     // iteration state
     int k = 0;

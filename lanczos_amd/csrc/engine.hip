@@ -141,6 +141,8 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
     n_global = opt.n_global ? opt.n_global : n;
     row_begin = opt.row_begin;
     if (reorth < 0 || reorth > LANCZOS_HIP_REORTH_FULL2) return fail("lanczos_hip_create: bad reorth mode %d", reorth);
+    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_PIPE_NT)
+        return fail("lanczos_hip_create: bad spmv_kernel %d", opt.spmv_kernel);
     if (opt.device >= 0) {
         HIP_TRY(hipSetDevice(opt.device));
         device = opt.device;
@@ -195,9 +197,17 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
     // ---- SpMV variant
     const double mean = (double)nnz / (double)n;
     spmv_kind = opt.spmv_kernel;
-    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) spmv_kind = LANCZOS_HIP_SPMV_STREAM;
+    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) spmv_kind = LANCZOS_HIP_SPMV_PIPE;
     group = pick_group(mean);
-    if (spmv_kind == LANCZOS_HIP_SPMV_STREAM)
+    // rows per wavefront group of the pipe kernel: the largest of 64,32,16,8,4,1
+    // whose typical nnz span still fits one tile
+    log2r = 6;
+    while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
+    if (log2r == 1) log2r = 0;
+    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)
+        snprintf(spmv_name, sizeof(spmv_name), "pipe%d%s%s", 1 << log2r,
+                 spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT ? "_nt" : "", rp64 ? "_rp64" : "");
+    else if (spmv_kind == LANCZOS_HIP_SPMV_STREAM)
         snprintf(spmv_name, sizeof(spmv_name), "stream%s", rp64 ? "_rp64" : "");
     else
         snprintf(spmv_name, sizeof(spmv_name), "vector%d%s", group, rp64 ? "_rp64" : "");
@@ -267,6 +277,34 @@ double Engine::spmv_bytes() const {
 template <typename RP>
 static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double *y, int *nparts) {
     const RP *rp = (const RP *)e->d_rp;
+    if (e->spmv_kind == LANCZOS_HIP_SPMV_PIPE || e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {
+        const int lr = e->log2r;
+        const int64_t groups = (e->n + (1 << lr) - 1) >> lr;
+        const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+        int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
+        *nparts = blocks;
+        const bool nt = e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT;
+#define LZ_PIPE_CASE(LR)                                                                                       \
+    case LR:                                                                                                   \
+        if (nt)                                                                                                \
+            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, true>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,   \
+                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials);                             \
+        else                                                                                                   \
+            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, false>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,  \
+                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials);                             \
+        break;
+        switch (lr) {
+            LZ_PIPE_CASE(6)
+            LZ_PIPE_CASE(5)
+            LZ_PIPE_CASE(4)
+            LZ_PIPE_CASE(3)
+            LZ_PIPE_CASE(2)
+            default:
+                LZ_PIPE_CASE(0)
+        }
+#undef LZ_PIPE_CASE
+        return;
+    }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_STREAM) {
         const int64_t groups = (e->n + 63) / 64;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -298,6 +336,12 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double
 
 int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *nparts) {
     ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
+    if (nnz == 0) {  // the zero matrix: y = 0, alpha = 0 (the kernels assume one valid entry)
+        HIP_TRY(hipMemsetAsync(y, 0, sizeof(double) * n, stream));
+        HIP_TRY(hipMemsetAsync(d_partials, 0, sizeof(double) * 8, stream));
+        *nparts = 8;
+        return 0;
+    }
     if (rp64)
         launch_spmv_t<int64_t>(this, x, xdot, y, nparts);
     else

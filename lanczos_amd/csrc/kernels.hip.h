@@ -116,14 +116,18 @@ k_spmv_vector(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
 // SpMV, "stream" form: one wavefront per group of 64 rows
 // ---------------------------------------------------------------------------
 //
-// The 65 row offsets of a group are read once (coalesced) and kept in LDS.
-// The wavefront then streams the group's nnz span [rp[g0], rp[g0+64]) in tiles
-// of kTile entries with fully coalesced col/val loads, gathers x, and parks the
-// products in LDS; lane r finally sums the slice of each tile that belongs to
-// row g0 + r.  Lanes never idle on short rows and col/val traffic is contiguous
-// whatever the row lengths are.  A row longer than a tile is summed across
-// tiles by its lane.
-constexpr int kTile = 512;  // products per wavefront tile (4 KiB of LDS)
+// Lane r of a wavefront owns row g0 + r of its group and loads that row's two
+// offsets (coalesced).  The wavefront then streams the group's nnz span
+// [rp[g0], rp[g0+64]) in tiles of kTile entries: all col/val loads of a tile
+// are issued back to back on clamped (always valid) indices, then all x
+// gathers, so one wavefront keeps 24 loads in flight with no branch between
+// them; the products are parked in LDS and lane r sums the slice of the tile
+// that belongs to its row.  Lanes never idle on short rows and col/val traffic
+// is contiguous whatever the row lengths are.  A row longer than a tile is
+// summed across tiles by its lane.  The offsets of the wavefront's next group
+// are fetched before the current group is processed.
+constexpr int kTileU = 8;            // 64-entry slices per tile
+constexpr int kTile = 64 * kTileU;   // products per wavefront tile (4 KiB of LDS)
 
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
@@ -132,7 +136,6 @@ k_spmv_stream(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
               const double *__restrict__ xdot, double *__restrict__ y,
               double *__restrict__ partials) {
     __shared__ double prod[kWavesPerBlock][kTile];
-    __shared__ RP offs[kWavesPerBlock][66];
     __shared__ double red[kWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -147,36 +150,45 @@ k_spmv_stream(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
     if (c_end > total) c_end = total;
     double acc = 0.0;
     double *myprod = prod[wave];
-    RP *myoffs = offs[wave];
-    for (int64_t c = xcd * per_xcd + slot; c < c_end; c += slots) {
-        const int64_t g = c * kWavesPerBlock + wave;
-        if (g >= groups) continue;  // wave-uniform
-        const int64_t g0 = g << 6;
-        const int64_t row = g0 + lane;
-        // stage the row offsets of this group
-        {
-            int64_t r = row < n ? row : n;
-            myoffs[lane] = rp[r];
-            if (lane == 0) {
-                int64_t last = g0 + 64 < n ? g0 + 64 : n;
-                myoffs[64] = rp[last];
-            }
+
+    int64_t c = xcd * per_xcd + slot;
+    // offsets of the first group (rows past the end read rp[n]: an empty row)
+    RP nxt_lo = 0, nxt_hi = 0;
+    if (c < c_end) {
+        const int64_t row = ((c * kWavesPerBlock + wave) << 6) + lane;
+        nxt_lo = rp[row < n ? row : n];
+        nxt_hi = rp[row + 1 < n ? row + 1 : n];
+    }
+    for (; c < c_end; c += slots) {
+        const int64_t row = ((c * kWavesPerBlock + wave) << 6) + lane;
+        const RP my_lo = nxt_lo, my_hi = nxt_hi;
+        if (c + slots < c_end) {
+            const int64_t nrow = (((c + slots) * kWavesPerBlock + wave) << 6) + lane;
+            nxt_lo = rp[nrow < n ? nrow : n];
+            nxt_hi = rp[nrow + 1 < n ? nrow + 1 : n];
         }
-        __builtin_amdgcn_wave_barrier();
-        const RP span_lo = myoffs[0];
-        const RP span_hi = myoffs[64];
-        const RP my_lo = myoffs[lane];
-        const RP my_hi = (row < n) ? myoffs[lane + 1] : my_lo;
-        // note: for rows >= n offs[lane] == rp[n] so my_lo == my_hi == span_hi
+        const double xd = xdot[row < n ? row : n - 1];
+        const RP span_lo = __shfl(my_lo, 0);
+        const RP span_hi = __shfl(my_hi, 63);
         double sum = 0.0;
         for (RP t0 = span_lo; t0 < span_hi; t0 += kTile) {
-            const RP t1 = (t0 + kTile < span_hi) ? (RP)(t0 + kTile) : span_hi;
+            const RP last = span_hi - 1;
+            int32_t cj[kTileU];
+            double vj[kTileU], xj[kTileU];
 #pragma unroll
-            for (int u = 0; u < kTile / 64; ++u) {
-                const RP j = t0 + u * 64 + lane;
-                if (j < t1) myprod[u * 64 + lane] = val[j] * x[col[j]];
+            for (int u = 0; u < kTileU; ++u) {
+                RP j = t0 + u * 64 + lane;
+                j = j < last ? j : last;
+                cj[u] = col[j];
+                vj[u] = val[j];
             }
+#pragma unroll
+            for (int u = 0; u < kTileU; ++u) xj[u] = x[cj[u]];
+#pragma unroll
+            for (int u = 0; u < kTileU; ++u) myprod[u * 64 + lane] = vj[u] * xj[u];
             __builtin_amdgcn_wave_barrier();
+            // entries past span_hi hold clamped duplicates; no row slice reaches them
+            const RP t1 = (span_hi - t0 > (RP)kTile) ? (RP)(t0 + kTile) : span_hi;
             const RP lo = my_lo > t0 ? my_lo : t0;
             const RP hi = my_hi < t1 ? my_hi : t1;
             for (RP j = lo; j < hi; ++j) sum += myprod[j - t0];
@@ -184,8 +196,148 @@ k_spmv_stream(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
         }
         if (row < n) {
             y[row] = sum;
-            acc += sum * xdot[row];
+            acc += sum * xd;
         }
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV, "pipe" form: the stream form, software pipelined across row groups
+// ---------------------------------------------------------------------------
+//
+// A wavefront owns groups of R = 2^LOG2R consecutive rows (lane r < R owns a
+// row; R is chosen on the host so that a typical group's nnz span fits one
+// tile).  SpMV has a two-deep dependent load chain (col -> x[col]); to keep
+// HBM busy through it, iteration i issues, in this order,
+//     the x gathers of group i            (its col/val were loaded during i-1)
+//     the row offsets of group i+2
+//     the col/val loads of group i+1      (its offsets were loaded during i-1)
+// and only then waits for the gathers of group i.  The hardware retires vector
+// loads in issue order, so that wait leaves the 18 younger loads in flight.
+// The loop body is branch-free for single-tile groups (indices are clamped to
+// valid entries instead of being predicated); spans longer than a tile take a
+// synchronous tail loop.
+template <typename RP, int LOG2R, bool NT>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+            const double *__restrict__ val, const double *__restrict__ x,
+            const double *__restrict__ xdot, double *__restrict__ y,
+            double *__restrict__ partials) {
+    __shared__ double prod[kWavesPerBlock][kTile];
+    __shared__ double red[kWavesPerBlock];
+    constexpr int R = 1 << LOG2R;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t groups = (n + R - 1) >> LOG2R;
+    const int64_t total = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (total + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > total) c_end = total;
+    const int64_t c0 = xcd * per_xcd + slot;
+    const int64_t count = c0 < c_end ? (c_end - c0 + slots - 1) / slots : 0;
+    double *myprod = prod[wave];
+    double acc = 0.0;
+
+    auto ld_col = [&](RP j) -> int32_t { return NT ? __builtin_nontemporal_load(col + j) : col[j]; };
+    auto ld_val = [&](RP j) -> double { return NT ? __builtin_nontemporal_load(val + j) : val[j]; };
+    // row owned by this lane in the wavefront's i-th group (n: none, an empty row)
+    auto row_of = [&](int64_t i) -> int64_t {
+        const int64_t r = (((c0 + i * slots) * kWavesPerBlock + wave) << LOG2R) + lane;
+        return (lane < R && r < n) ? r : n;
+    };
+    auto offsets = [&](int64_t r, RP &lo, RP &hi) {
+        lo = rp[r];
+        hi = rp[r < n ? r + 1 : n];
+    };
+
+    // issue the col loads, then the val loads, of the first tile of a span
+    auto issue_colval = [&](RP s_lo, RP s_hi, int32_t (&cj)[kTileU], double (&vj)[kTileU]) {
+        // `last` is a valid entry whenever nnz > 0 (the host never launches this kernel on nnz == 0)
+        const RP last = s_hi > s_lo ? s_hi - 1 : (s_lo > 0 ? s_lo - 1 : 0);
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            RP j = s_lo + u * 64 + lane;
+            j = j < last ? j : last;
+            cj[u] = ld_col(j);
+        }
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            RP j = s_lo + u * 64 + lane;
+            j = j < last ? j : last;
+            vj[u] = ld_val(j);
+        }
+    };
+    // One pipeline step for group i.  (lo_c, hi_c) hold its offsets on entry and the
+    // offsets of group i+2 on exit; (lo_n, hi_n) are the offsets of group i+1;
+    // (c_c, v_c) hold its first tile, (c_n, v_n) receive the first tile of group i+1.
+    // The two register sets alternate between steps so that no loaded value is ever
+    // copied (a copy would have to wait for the load and drain the queue).
+    auto step = [&](int64_t i, int32_t (&c_c)[kTileU], double (&v_c)[kTileU], int32_t (&c_n)[kTileU],
+                    double (&v_n)[kTileU], RP &lo_c, RP &hi_c, const RP &lo_n, const RP &hi_n) {
+        const int64_t row = row_of(i);
+        const RP my_lo = lo_c, my_hi = hi_c;
+        const RP span_lo = __shfl(my_lo, 0), span_hi = __shfl(my_hi, R - 1);
+        // (a) gathers of this group
+        double xj[kTileU];
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) xj[u] = x[c_c[u]];
+        const double xd = xdot[row < n ? row : n - 1];
+        // (b) offsets of group i+2 (clamped to the last group)
+        offsets(row_of(i + 2 < count ? i + 2 : count - 1), lo_c, hi_c);
+        // (c) col/val of group i+1 (when there is none: a harmless reload of valid entries)
+        issue_colval(__shfl(lo_n, 0), __shfl(hi_n, R - 1), c_n, v_n);
+        // (d) products of this group's first tile -> LDS -> per-row sums
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) myprod[u * 64 + lane] = v_c[u] * xj[u];
+        __builtin_amdgcn_wave_barrier();
+        double sum = 0.0;
+        {
+            const RP t1 = (span_hi - span_lo > (RP)kTile) ? (RP)(span_lo + kTile) : span_hi;
+            const RP hi = my_hi < t1 ? my_hi : t1;
+            for (RP j = my_lo; j < hi; ++j) sum += myprod[j - span_lo];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // rare: the span does not fit one tile
+        for (RP t0 = span_lo + kTile; t0 < span_hi; t0 += kTile) {
+            const RP last = span_hi - 1;
+#pragma unroll
+            for (int u = 0; u < kTileU; ++u) {
+                RP j = t0 + u * 64 + lane;
+                j = j < last ? j : last;
+                myprod[u * 64 + lane] = val[j] * x[col[j]];
+            }
+            __builtin_amdgcn_wave_barrier();
+            const RP t1 = (span_hi - t0 > (RP)kTile) ? (RP)(t0 + kTile) : span_hi;
+            const RP lo = my_lo > t0 ? my_lo : t0;
+            const RP hi = my_hi < t1 ? my_hi : t1;
+            for (RP j = lo; j < hi; ++j) sum += myprod[j - t0];
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (row < n) {
+            y[row] = sum;
+            acc += sum * xd;
+        }
+    };
+
+    if (count > 0) {
+        // ---- prologue: offsets of groups 0 and 1, col/val of group 0
+        RP loA, hiA, loB, hiB;
+        offsets(row_of(0), loA, hiA);
+        offsets(row_of(count > 1 ? 1 : 0), loB, hiB);
+        int32_t cA[kTileU], cB[kTileU];
+        double vA[kTileU], vB[kTileU];
+        issue_colval(__shfl(loA, 0), __shfl(hiA, R - 1), cA, vA);
+        int64_t i = 0;
+        for (; i + 1 < count; i += 2) {
+            step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
+            step(i + 1, cB, vB, cA, vA, loB, hiB, loA, hiA);
+        }
+        if (i < count) step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
     }
     const double total_acc = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;

@@ -7,7 +7,7 @@ for (d,N,steps) in ((1,10000,30),(3,24,30),(2,100,30)):
     v0=la.gaussian_fill(123456789,0,n)
     x=np.random.default_rng(1).standard_normal(n)
     yo=oracle.matvec_crs(A.row_head_indexes,A.column_index,A.values,x)
-    for spmv in ("vector","stream"):
+    for spmv in ("vector","stream","pipe","pipe_nt"):
         for reorth in ("full","mgs","full2","none","cuda_compat"):
             with la.Engine(A,steps+1,reorth=reorth,spmv=spmv) as e:
                 y=e.spmv(x)

@@ -1,0 +1,291 @@
+"""Parity of the HIP path with the CPU restatement, through the C ABI.
+
+Every test here runs on an MI355X (-m gpu).  Tolerances: SpMV within a few ulp of
+the row's |a||x| sum; alpha/beta of the first 20 steps 1e-12 relative; Ritz values
+1e-10 relative (the parity bar of the reference comparison), with an absolute
+floor of 1e-10 * ||T|| where an eigenvalue may be ~0."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import lanczos_amd as la
+import oracle
+from matrices import laplacian3d_triplets_by_column, laplacian_eigs, laplacian_triplets_rowwise, rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SPMV_KINDS = ["vector", "stream", "pipe", "pipe_nt"]
+
+
+def crs_from_scipy(m):
+    m = m.tocsr()
+    return la.CrsMatrix(m.data.astype(np.float64), m.indices.astype(np.int64), m.indptr.astype(np.int64))
+
+
+def irregular_matrix(n, seed, long_rows=()):
+    """Row lengths from 0 to ~60 plus a few very long rows; unsorted columns, duplicates."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 60, n)
+    lens[rng.integers(0, n, n // 10)] = 0             # empty rows
+    for r, L in long_rows:
+        lens[r] = L
+    head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    cols = rng.integers(0, n, head[-1]).astype(np.int64)
+    vals = rng.standard_normal(head[-1])
+    return la.CrsMatrix(vals, cols, head)
+
+
+def spmv_tolerance(a, x):
+    absrow = oracle.matvec_crs(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x))
+    maxlen = int(np.diff(a.row_head_indexes).max()) if a.dimension else 1
+    return (maxlen + 4) * np.finfo(float).eps * absrow + 1e-300
+
+
+@pytest.mark.parametrize("kind", SPMV_KINDS)
+def test_spmv_matches_oracle_on_laplacians(gpu, kind):
+    for d, N in ((1, 1000), (1, 4097), (2, 67), (3, 20)):
+        a = la.synth_laplacian(d, N)
+        x = np.random.default_rng(d).standard_normal(a.dimension)
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        with la.Engine(a, 3, spmv=kind) as e:
+            got = e.spmv(x)
+        assert np.all(np.abs(got - want) <= spmv_tolerance(a, x)), (d, N, kind)
+
+
+@pytest.mark.parametrize("kind", SPMV_KINDS)
+def test_spmv_matches_oracle_on_irregular_rows(gpu, kind):
+    # empty rows, rows longer than one 512-entry tile, n not a multiple of 64, trailing empty rows
+    for n, seed, long_rows in ((1, 0, ()), (63, 1, ()), (65, 2, ((3, 700),)), (1000, 3, ((0, 2000), (999, 513), (500, 512))),
+                               (5000, 4, ((4999, 0), (4998, 0), (77, 5000)))):
+        a = irregular_matrix(n, seed, long_rows)
+        x = np.random.default_rng(seed + 100).standard_normal(n)
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        with la.Engine(a, 3, spmv=kind) as e:
+            got = e.spmv(x)
+        assert np.all(np.abs(got - want) <= spmv_tolerance(a, x)), (n, kind)
+
+
+def test_spmv_zero_matrix_and_auto_kernel(gpu):
+    n = 300
+    a = la.CrsMatrix(np.zeros(0), np.zeros(0, np.int64), np.zeros(n + 1, np.int64))
+    with la.Engine(a, 3) as e:
+        assert np.all(e.spmv(np.ones(n)) == 0.0)
+    r = la.synth_random_symmetric(20000, 10, 42)       # ~21 nnz per row: 16 rows per wavefront group
+    with la.Engine(r, 3) as e:
+        assert e.spmv_name == "pipe16"
+        x = np.random.default_rng(9).standard_normal(r.dimension)
+        want = oracle.matvec_crs(r.row_head_indexes, r.column_index, r.values, x)
+        assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(r, x))
+    with la.Engine(la.synth_laplacian(3, 16), 3) as e:
+        assert e.spmv_name == "pipe64"
+
+
+def test_create_rejects_bad_matrices(gpu):
+    a = la.synth_laplacian(1, 100)
+    bad = la.CrsMatrix(a.values, a.column_index.copy(), a.row_head_indexes)
+    bad.column_index[5] = 100                          # out of range: would be an out-of-bounds gather
+    with pytest.raises(la.LanczosHipError, match="column index out of range"):
+        la.Engine(bad, 3)
+    bad = la.CrsMatrix(a.values, a.column_index, a.row_head_indexes.copy())
+    bad.row_head_indexes[10] = bad.row_head_indexes[11] + 1
+    with pytest.raises(la.LanczosHipError, match="not monotone"):
+        la.Engine(bad, 3)
+    with pytest.raises(la.LanczosHipError, match="max_iter must be >= 2"):
+        la.Engine(a, 1)
+
+
+REORTH_TO_ORACLE = {"full": "full", "mgs": "full", "full2": "full", "none": "none", "cuda_compat": "cuda_compat"}
+
+
+@pytest.mark.parametrize("reorth", list(REORTH_TO_ORACLE))
+def test_alpha_beta_sequences_match_oracle(gpu, reorth):
+    for a in (la.synth_laplacian(1, 10000), la.synth_laplacian(2, 100), la.synth_laplacian(3, 24),
+              la.synth_random_symmetric(3000, 10, 7)):
+        v0 = la.gaussian_fill(123456789, 0, a.dimension)
+        steps = 20
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0,
+                               REORTH_TO_ORACLE[reorth])
+        with la.Engine(a, steps + 1, reorth=reorth) as e:
+            e.set_start(v0)
+            alpha, beta = e.run(steps)
+        assert rel_err(alpha, o.alpha) < 1e-12 and rel_err(beta, o.beta) < 1e-12, reorth
+
+
+@pytest.mark.parametrize("reorth", ["full", "mgs", "full2"])
+def test_ritz_values_at_100_steps_match_oracle(gpu, reorth):
+    """The reference's CPU-runnable configuration: ~10k rows, 100 Lanczos steps, 4 values."""
+    for a in (la.synth_laplacian(1, 10000), la.synth_laplacian(2, 100)):
+        v0 = la.gaussian_fill(123456789, 0, a.dimension)
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 101)
+        with la.Engine(a, 101, reorth=reorth) as e:
+            e.set_start(v0)
+            alpha, beta = e.run(100)
+        ritz = la.ritz_values(alpha, beta, 100, 4)
+        assert rel_err(ritz, o.eigenvalues) < 1e-10
+        # every intermediate step too (what the reference prints per iteration)
+        for k in (1, 2, 3, 10, 50, 99):
+            assert rel_err(la.ritz_values(alpha, beta, k, 4)[:min(k, 4)], o.ritz_hist[k - 1][:min(k, 4)]) < 1e-10
+
+
+def _known(golden_dir, name, threads):
+    cases = json.load(open(os.path.join(golden_dir, "reference_known_answers.json")))["cases"]
+    return [c for c in cases if c["name"] == name and c["threads"] == threads][0]
+
+
+def test_gpu_reproduces_the_references_recorded_ritz_values(gpu, golden_dir):
+    """GPU against numbers the unmodified reference printed (not against the oracle)."""
+    # 1-D, n = 10000, triplets -> convert_from_coo(swap=1) through the product's host code
+    n = 10000
+    r, c, v = laplacian_triplets_rowwise(n)
+    coo = np.zeros(r.size, la.COO_DTYPE)
+    coo["index_row"], coo["index_column"], coo["value"] = r, c, v
+    a = la.convert_from_coo(coo, n, 1)
+    with la.Engine(a, 100) as e:
+        e.set_start(oracle.xorshift_start(n))
+        alpha, beta = e.run(99)
+    assert rel_err(la.ritz_values(alpha, beta, 99, 4), _known(golden_dir, "lap1d_10000", 1)["eig"]) < 1e-10
+    # 3-D 64^3, max_iter = 101
+    N = 64
+    r, c, v = laplacian3d_triplets_by_column(N)
+    coo = np.zeros(r.size, la.COO_DTYPE)
+    coo["index_row"], coo["index_column"], coo["value"] = r, c, v
+    a = la.convert_from_coo(coo, N ** 3, 1)
+    with la.Engine(a, 101) as e:
+        e.set_start(oracle.xorshift_start(N ** 3))
+        alpha, beta = e.run(100)
+    assert rel_err(la.ritz_values(alpha, beta, 100, 4), _known(golden_dir, "lap3d_64", 1)["eig"]) < 1e-10
+    # 3-D 128^3, max_iter = 51
+    N = 128
+    r, c, v = laplacian3d_triplets_by_column(N)
+    coo = np.zeros(r.size, la.COO_DTYPE)
+    coo["index_row"], coo["index_column"], coo["value"] = r, c, v
+    a = la.convert_from_coo(coo, N ** 3, 1)
+    with la.Engine(a, 51) as e:
+        e.set_start(oracle.xorshift_start(N ** 3))
+        alpha, beta = e.run(50)
+    assert rel_err(la.ritz_values(alpha, beta, 50, 4), _known(golden_dir, "lap3d_128", 8)["eig"]) < 1e-10
+
+
+def test_basis_is_orthonormal_and_runs_are_bitwise_repeatable(gpu):
+    a = la.synth_laplacian(3, 20)
+    v0 = la.gaussian_fill(5, 0, a.dimension)
+    with la.Engine(a, 61) as e:
+        e.set_start(v0)
+        alpha, beta = e.run(60)
+        V = np.stack([e.get_vector(k) for k in range(61)])
+        gram = V @ V.T
+        assert np.max(np.abs(gram - np.eye(61))) < 1e-12
+        # T = V A V^T is tridiagonal with alpha on the diagonal and beta beside it
+        AV = np.stack([oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, V[k]) for k in range(60)])
+        T = V[:60] @ AV.T
+        assert np.max(np.abs(np.diag(T) - alpha)) < 1e-12
+        assert np.max(np.abs(np.diag(T, 1) - beta[:59])) < 1e-12
+        e.set_start(v0)
+        alpha2, beta2 = e.run(60)
+        assert alpha.tobytes() == alpha2.tobytes() and beta.tobytes() == beta2.tobytes()
+
+
+def test_converged_values_match_closed_form(gpu):
+    a = la.synth_laplacian(2, 40)
+    with la.Engine(a, 400) as e:
+        e.set_start_seed(3)
+        alpha, beta = e.run(399)
+    exact = laplacian_eigs(2, 40, 2)
+    got = la.ritz_values(alpha, beta, 399, 2)
+    assert abs(got[0] - exact[0]) < 1e-10 * exact[0]
+
+
+def test_engine_limits(gpu):
+    a = la.synth_laplacian(1, 500)
+    with la.Engine(a, 5) as e:
+        with pytest.raises(la.LanczosHipError, match="no start vector"):
+            e.run(1)
+        e.set_start_seed(1)
+        e.run(4)
+        with pytest.raises(la.LanczosHipError, match="basis full"):
+            e.run(1)
+    with la.Engine(a, 5, reorth="none") as e:          # ring of 3 vectors: not bounded by max_iter
+        e.set_start_seed(1)
+        alpha, beta = e.run(50)
+        assert np.all(np.isfinite(alpha)) and np.all(beta > 0)
+
+
+def run_dropin(a, nth, max_iter, threshold, env=None):
+    """lanczos_hip_crs() in a child process so that its stdout/stderr can be read."""
+    code = (
+        "import sys, json, numpy as np, lanczos_amd as la\n"
+        "d=np.load(sys.argv[1])\n"
+        "a=la.CrsMatrix(d['v'],d['c'],d['h'])\n"
+        f"rc,eig=la.lanczos_hip_crs(a,{nth},{max_iter},{threshold!r})\n"
+        "sys.stdout.flush()\n"
+        "print('RESULT '+json.dumps({'rc':rc,'eig':[float(x) for x in eig]}))\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.npz")
+        np.savez(path, v=a.values, c=a.column_index, h=a.row_head_indexes)
+        full_env = dict(os.environ)
+        full_env.update(env or {})
+        r = subprocess.run(["python", "-c", code, path], cwd=ROOT, capture_output=True, text=True, env=full_env,
+                           timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    return res, r.stdout, r.stderr
+
+
+def test_dropin_matches_oracle_and_prints_reference_lines(gpu):
+    a = la.synth_laplacian(2, 100)
+    v0 = la.gaussian_fill(123456789, 0, a.dimension)   # the drop-in's default seed
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 101, 0.0)
+    res, out, err = run_dropin(a, 4, 101, 0.0)
+    assert res["rc"] == 0
+    assert rel_err(res["eig"], o.eigenvalues) < 1e-10
+    lines = out.splitlines()
+    assert "Reached max iterations (101)" in lines
+    step_lines = [ln for ln in lines if ln[:1].isdigit() and "\t" in ln]
+    assert len(step_lines) == 100 and step_lines[0].split("\t")[0] == "1"
+    want = "\t".join(f"{x:.7f}" for x in o.ritz_hist[49])
+    assert step_lines[49] == "50\t" + want + "\t"
+    for name in ("init", "spmv", "diagonalization", "reorthogonalization"):
+        assert f"[TOTAL] name={name}" in err
+
+
+def test_dropin_convergence_exits_follow_the_cpu_rule(gpu):
+    a = la.synth_laplacian(1, 2000)
+    v0 = la.gaussian_fill(123456789, 0, a.dimension)
+    for thr in (10e-5, 1e-2):
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 2, 400, thr)
+        res, out, _ = run_dropin(a, 2, 400, thr, env={"LANCZOS_HIP_QUIET": "1"})
+        assert res["rc"] == 0
+        if o.exit_kind == 1:
+            assert "converged " in out
+        # same exit step => same values to parity tolerance; the exit step itself may differ by
+        # one where a difference sits within rounding of the threshold, so compare to it loosely
+        assert rel_err(res["eig"], o.eigenvalues) < 1e-6
+    # bad arguments: EXIT_FAILURE and the reference's message (src/lanczos_cuda.c:324-327)
+    res, out, _ = run_dropin(a, 2, 1, 0.0)
+    assert res["rc"] == 1 and "max_iter must be >= 2" in out
+
+
+def test_driver_binary_on_triplet_file(gpu, tmp_path):
+    """main -> read_mat_coo_incremental -> convert_from_coo(swap=1) -> lanczos_hip_crs."""
+    n = 10000
+    r, c, v = laplacian_triplets_rowwise(n)
+    path = tmp_path / "lap1d.txt"
+    with open(path, "w") as f:
+        f.write("".join(f"{i + 1} {j + 1} {x:g}\n" for i, j, x in zip(r, c, v)))
+    exe = os.path.join(ROOT, "lanczos_amd", "bin", "lanczos_main")
+    coo = np.zeros(r.size, oracle.COO_DTYPE)
+    coo["row"], coo["col"], coo["val"] = r, c, v
+    vals, cols, head = oracle.coo_to_crs(coo, n, 1)
+    v0 = la.gaussian_fill(123456789, 0, n)
+    o = oracle.lanczos_crs(head, cols, vals, v0, 4, 101, 10e-5)
+    for mode in ("crs_hip", "crs", "coo"):
+        p = subprocess.run([exe, str(path), mode, "4", "101"], capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1000:]
+        assert f"mat dim: {n}" in p.stdout and f"mat num-of-non-zero: {r.size}" in p.stdout
+        eig = [float(ln.split("\t")[-1]) for ln in p.stdout.splitlines() if ln.startswith("eigenvalue")]
+        assert len(eig) == 4
+        assert np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12   # printed at %.12f

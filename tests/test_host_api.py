@@ -1,0 +1,156 @@
+"""Host-side C API of the product (lanczos_amd/host, include/lanczos_host.h and
+the host-only parts of include/lanczos_hip.h) against the reference's outputs
+and the oracle.  No GPU needed: nothing here launches a kernel."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import lanczos_amd as la
+import oracle
+from test_oracle_golden import CASES, read_ref_bin
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("swap", [0, 1])
+def test_ingest_and_convert_from_coo_bit_exact(golden_dir, name, swap):
+    ref = read_ref_bin(os.path.join(golden_dir, f"ref_{name}_swap{swap}.bin"))
+    coo, dim = la.read_mat_coo_incremental(os.path.join(golden_dir, f"triplets_{name}.txt"))
+    assert dim == ref["dim"]
+    assert coo.tobytes() == ref["coo"].tobytes()
+    a = la.convert_from_coo(coo, dim, swap)
+    assert a.values.tobytes() == ref["values"].tobytes()
+    assert a.column_index.tobytes() == ref["cols"].tobytes()
+    assert a.row_head_indexes.tobytes() == ref["head"].tobytes()
+    y = la.matvec_crs(a, ref["x"])
+    scale = np.abs(ref["y_crs"]).max() + 1.0
+    assert np.max(np.abs(y - ref["y_crs"])) <= 4 * np.finfo(float).eps * scale
+
+
+def test_convert_from_coo_large_random_matches_oracle():
+    rng = np.random.default_rng(5)
+    n, m = 5000, 200000
+    coo = np.zeros(m, la.COO_DTYPE)
+    coo["index_row"] = rng.integers(0, n, m)
+    coo["index_column"] = rng.integers(0, n, m)
+    coo["value"] = rng.standard_normal(m)
+    for swap in (0, 1):
+        a = la.convert_from_coo(coo, n, swap)
+        v, c, h = oracle.coo_to_crs(coo.view(oracle.COO_DTYPE), n, swap)
+        assert a.values.tobytes() == v.tobytes() and a.column_index.tobytes() == c.tobytes()
+        assert a.row_head_indexes.tobytes() == h.tobytes()
+
+
+def _run_py(code):
+    return subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True)
+
+
+def test_error_behaviour_is_exit_with_message():
+    # out-of-range index: stderr message + exit(EXIT_FAILURE), src/crs.c:68-77
+    r = _run_py("import numpy as np, lanczos_amd as la\n"
+                "c=np.zeros(1,la.COO_DTYPE); c['index_row']=7\n"
+                "la.convert_from_coo(c,3,0)\n")
+    assert r.returncode == 1 and "convert_from_coo: index out of range at entry 0 (row=7, col=0, dim=3)" in r.stderr
+    # malformed line: src/coo.c:19-22
+    r = _run_py("import lanczos_amd as la\nla.parse_to_coo('abc 1 2')\n")
+    assert r.returncode == 1 and "Error: Invalid integer abc 1 2" in r.stderr
+    # missing file: perror + exit, src/coo.c:113-117
+    r = _run_py("import lanczos_amd as la\nla.read_mat_coo_incremental('/nonexistent/file.txt')\n")
+    assert r.returncode == 1 and "fopen" in r.stderr
+
+
+def test_parse_to_coo_forms():
+    assert la.parse_to_coo("3 4 1.5") == (2, 3, 1.5)
+    assert la.parse_to_coo("  7\t9   -2e-3") == (6, 8, -2e-3)
+    for line in ("3 4 1.5", " 12   1 1E+2", "5 5 -0.0"):
+        rc, r, c, v = oracle.parse_line(line)
+        assert (r, c, v) == la.parse_to_coo(line)
+
+
+def test_tridiag_eigs_against_mkl_and_oracle(golden_dir):
+    data = json.load(open(os.path.join(golden_dir, "mkl_dsyevr.json")))
+    for case in data["cases"]:
+        alpha, beta = np.array(case["alpha"]), np.array(case["beta"])
+        n = alpha.size
+        eig = la.tridiag_eigs(alpha, beta, n, case["nth"])
+        tnorm = np.abs(alpha).max() + 2 * (np.abs(beta).max() if n > 1 else 0.0)
+        iu = min(case["nth"], n)
+        assert np.max(np.abs(eig[:iu] - np.array(case["eig"]))) <= 64 * np.finfo(float).eps * tnorm
+        assert np.all(eig[iu:] == 0.0)
+        if case["kind"] == "toeplitz":   # closed form, and relative accuracy of the tiny ones
+            exact = 2 - 2 * np.cos(np.pi * np.arange(1, iu + 1) / (n + 1))
+            assert np.max(np.abs(eig[:iu] - exact) / exact) < 1e-11
+
+
+def test_gaussian_fill_is_partition_invariant_and_normal():
+    g = la.gaussian_fill(123456789, 0, 200000)
+    assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
+    assert np.array_equal(la.gaussian_fill(123456789, 777, 1000), g[777:1777])
+    assert not np.array_equal(la.gaussian_fill(1, 0, 100), g[:100])
+
+
+def test_synthetic_matrices():
+    import scipy.sparse as sp
+    for d, N in ((1, 50), (2, 12), (3, 7)):
+        a = la.synth_laplacian(d, N)
+        n = N ** d
+        m = sp.csr_matrix((a.values, a.column_index, a.row_head_indexes), shape=(n, n))
+        assert abs(m - m.T).max() == 0 and np.all(m.diagonal() == 2 * d)
+        assert np.all(np.diff(a.row_head_indexes) == np.asarray((m != 0).sum(1)).ravel())
+        for i in range(n):   # ascending columns inside a row
+            seg = a.column_index[a.row_head_indexes[i]:a.row_head_indexes[i + 1]]
+            assert np.all(np.diff(seg) > 0)
+    r = la.synth_random_symmetric(2000, 10, 42)
+    m = sp.csr_matrix((r.values, r.column_index, r.row_head_indexes), shape=(2000, 2000))
+    assert abs(m - m.T).max() == 0
+    off = abs(m).sum(1).A.ravel() - m.diagonal()
+    assert np.allclose(m.diagonal(), 1 + off)
+    assert 18 < r.length / 2000 < 22
+
+
+def _declared_functions(header):
+    text = open(header).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"#define\b.*?(?<!\\)\n", "\n", text.replace("\\\n", " "))
+    return sorted(set(re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{}]*\)\s*;", text)) - {"Matvec_General"})
+
+
+def test_every_declared_symbol_is_exported():
+    hip = ctypes.CDLL(la.LIB_HIP)
+    host = ctypes.CDLL(la.LIB_HOST)
+    names = _declared_functions(os.path.join(ROOT, "include", "lanczos_hip.h"))
+    assert "lanczos_hip_crs" in names and "lanczos_hip_create" in names and len(names) >= 20
+    for name in names:
+        assert hasattr(hip, name), f"{name} declared in lanczos_hip.h but not exported"
+    names = _declared_functions(os.path.join(ROOT, "include", "lanczos_host.h"))
+    assert "convert_from_coo" in names and "lanczos" in names
+    for name in names:
+        assert hasattr(host, name), f"{name} declared in lanczos_host.h but not exported"
+
+
+def test_driver_usage_line():
+    exe = os.path.join(ROOT, "lanczos_amd", "bin", "lanczos_main")
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1
+    assert "<input_file> <coo|crs|crs_hip> <number_of_eigenvalues> <max_iter>" in r.stderr
+
+
+def test_product_does_not_reach_into_the_oracle():
+    """The product tree must not import, link or dlopen anything under oracle/."""
+    bad = []
+    for base, _, files in os.walk(os.path.join(ROOT, "lanczos_amd")):
+        if os.sep + "build" in base:
+            continue
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp", "Makefile")):
+                text = open(os.path.join(base, f), errors="replace").read()
+                if re.search(r"\boracle\b", text):
+                    bad.append(os.path.join(base, f))
+    assert not bad, bad
