@@ -50,7 +50,9 @@ def parse_args():
     ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none"])
     ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the row-partitioned code path even with one rank (rehearsal)")
+    ap.add_argument("--cpu-steps", type=int, default=100)
     return ap.parse_args()
 
 
@@ -203,7 +205,7 @@ def single_gpu(args) -> dict:
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or args.force_dist:
         from lanczos_amd.dist import bench_distributed
         out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS)
         if out is not None:

@@ -249,9 +249,13 @@ const char *lanczos_hip_last_error(void);
  */
 int lanczos_hip_phase_spmv(lanczos_hip_engine *e, double *red);
 int lanczos_hip_phase_recur(lanczos_hip_engine *e, double *red, int *n_red, int *is_norm);
+/* second Gram-Schmidt pass (LANCZOS_HIP_REORTH_FULL2): red[0..nl) = local V_l . w again */
+int lanczos_hip_phase_dots(lanczos_hip_engine *e, double *red, int *n_red);
 int lanczos_hip_phase_update(lanczos_hip_engine *e, double *red);
 int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red);
 double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k);
+/* Enqueue a device-to-device copy of basis vector k's local slab (n doubles) to dst. */
+int lanczos_hip_export_vector(lanczos_hip_engine *e, int k, double *dst_device);
 /* v_0 = scale * v0_host, for a caller that has reduced the norm across ranks. */
 int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, double scale);
 /* Copy alpha/beta history [0, iterations) from the device (row-partitioned

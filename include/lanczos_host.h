@@ -72,6 +72,9 @@ void lanczos(const Mat_Matvec mat_matvec, double eigenvalues[], double *eigenvec
  * lanczos_free_crs.  Returns 0 on success.
  */
 int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out);
+/* Rows [row_begin, row_end) of the same matrix (column indices stay global), for
+ * row-partitioned runs that never hold the whole matrix on one host. */
+int lanczos_synth_laplacian_rows(int d, int64_t N, int64_t row_begin, int64_t row_end, Mat_Crs *out);
 /*
  * Random sparse symmetric matrix: for every row `per_row` column draws uniform
  * in [0, n) from a counter-based generator, values uniform in (-1, 1), pattern

@@ -94,6 +94,10 @@ for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip
     getattr(_hip, _name).restype = C.c_int
 _hip.lanczos_hip_phase_recur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _hip.lanczos_hip_phase_recur.restype = C.c_int
+_hip.lanczos_hip_phase_dots.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+_hip.lanczos_hip_phase_dots.restype = C.c_int
+_hip.lanczos_hip_export_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+_hip.lanczos_hip_export_vector.restype = C.c_int
 _hip.lanczos_hip_local_vector.argtypes = [C.c_void_p, C.c_int]
 _hip.lanczos_hip_local_vector.restype = C.c_void_p
 _hip.lanczos_hip_history.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
@@ -111,6 +115,8 @@ _host.matvec_coo.argtypes = [C.POINTER(Mat_Coo), _dp, _dp]
 _host.matvec_coo.restype = None
 _host.lanczos_synth_laplacian.argtypes = [C.c_int, C.c_int64, C.POINTER(Mat_Crs)]
 _host.lanczos_synth_laplacian.restype = C.c_int
+_host.lanczos_synth_laplacian_rows.argtypes = [C.c_int, C.c_int64, C.c_int64, C.c_int64, C.POINTER(Mat_Crs)]
+_host.lanczos_synth_laplacian_rows.restype = C.c_int
 _host.lanczos_synth_random_symmetric.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.POINTER(Mat_Crs)]
 _host.lanczos_synth_random_symmetric.restype = C.c_int
 _host.lanczos_free_crs.argtypes = [C.POINTER(Mat_Crs)]
@@ -195,6 +201,14 @@ def synth_laplacian(d: int, N: int) -> CrsMatrix:
     m = Mat_Crs()
     if _host.lanczos_synth_laplacian(d, N, C.byref(m)) != 0:
         raise ValueError(f"lanczos_synth_laplacian({d}, {N}) failed")
+    return CrsMatrix._take(m)
+
+
+def synth_laplacian_rows(d: int, N: int, row_begin: int, row_end: int) -> CrsMatrix:
+    """Rows [row_begin, row_end) of synth_laplacian(d, N); column indices stay global."""
+    m = Mat_Crs()
+    if _host.lanczos_synth_laplacian_rows(d, N, row_begin, row_end, C.byref(m)) != 0:
+        raise ValueError(f"lanczos_synth_laplacian_rows({d}, {N}, {row_begin}, {row_end}) failed")
     return CrsMatrix._take(m)
 
 
@@ -324,6 +338,14 @@ class Engine:
         _check(_hip.lanczos_hip_phase_recur(self._h, red, C.byref(n_red), C.byref(is_norm)),
                "lanczos_hip_phase_recur")
         return n_red.value, bool(is_norm.value)
+
+    def phase_dots(self, red: int) -> int:
+        n_red = C.c_int(0)
+        _check(_hip.lanczos_hip_phase_dots(self._h, red, C.byref(n_red)), "lanczos_hip_phase_dots")
+        return n_red.value
+
+    def export_vector(self, k: int, dst: int):
+        _check(_hip.lanczos_hip_export_vector(self._h, k, dst), "lanczos_hip_export_vector")
 
     def phase_update(self, red: int):
         _check(_hip.lanczos_hip_phase_update(self._h, red), "lanczos_hip_phase_update")

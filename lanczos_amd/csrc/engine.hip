@@ -681,6 +681,17 @@ int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red) {
     if (!e || !red) return lz::fail("lanczos_hip_phase_scale: NULL argument");
     return E(e)->phase_scale(red);
 }
+int lanczos_hip_phase_dots(lanczos_hip_engine *e, double *red, int *n_red) {
+    if (!e || !red || !n_red) return lz::fail("lanczos_hip_phase_dots: NULL argument");
+    return E(e)->phase_dots(red, n_red);
+}
+int lanczos_hip_export_vector(lanczos_hip_engine *e, int k, double *dst_device) {
+    if (!e || !dst_device || k < 0) return lz::fail("lanczos_hip_export_vector: bad argument");
+    Engine *g = E(e);
+    if (hipMemcpyAsync(dst_device, g->vec(k), sizeof(double) * g->n, hipMemcpyDeviceToDevice, g->stream) != hipSuccess)
+        return lz::fail("lanczos_hip_export_vector: copy failed");
+    return 0;
+}
 double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k) {
     if (!e || k < 0) return nullptr;
     return E(e)->vec(k);

@@ -1,0 +1,432 @@
+"""Row-partitioned Lanczos over several GPUs of one node: one process per GPU,
+collectives through torch.distributed (backend "nccl" = RCCL over xGMI).
+
+The reference has no multi-GPU code; the only thing to agree with is the
+single-GPU result.  The matrix is cut into contiguous row slabs.  Per iteration
+the ranks exchange the current Lanczos vector (halo exchange with the two
+neighbouring slabs when the matrix is banded, all-gather otherwise) and
+all-reduce three small buffers: alpha, the reorthogonalisation coefficients,
+and beta^2.  Everything else runs inside each rank's engine through the
+phase-level C ABI (include/lanczos_hip.h).
+
+The host logic here (partition, column remap, exchange plan, iteration order)
+does not touch the GPU itself; it drives any object with the phase interface,
+which is how the CPU tests exercise it with the gloo backend.
+"""
+from __future__ import annotations
+
+import os
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+
+def partition_rows(n: int, world: int) -> list[int]:
+    """Contiguous slabs: rank p owns rows [b[p], b[p+1])."""
+    return [(p * n) // world for p in range(world + 1)]
+
+
+def partition_rows_by_nnz(row_head: np.ndarray, world: int) -> list[int]:
+    """Contiguous slabs with about equal nnz (for irregular matrices)."""
+    n = row_head.shape[0] - 1
+    nnz = int(row_head[-1])
+    cuts = [0]
+    for p in range(1, world):
+        cuts.append(int(np.searchsorted(row_head, (p * nnz) // world, side="left")))
+    cuts.append(n)
+    for p in range(1, world + 1):
+        cuts[p] = max(cuts[p], cuts[p - 1])
+    return cuts
+
+
+@dataclass
+class SlabPlan:
+    """How one rank's slab addresses the vector it multiplies with."""
+    mode: str            # "halo" or "allgather"
+    n_local: int
+    n_ext: int           # length of the SpMV input buffer
+    row_begin: int
+    halo_lo: int         # entries needed from the end of the previous slab
+    halo_hi: int         # entries needed from the start of the next slab
+    column_index: np.ndarray  # remapped into [0, n_ext)
+
+
+def needed_halo(cols: np.ndarray, row_begin: int, row_end: int) -> tuple[int, int]:
+    """(how far below row_begin, how far beyond row_end) the slab's columns reach."""
+    if cols.size == 0:
+        return 0, 0
+    lo = int(cols.min())
+    hi = int(cols.max())
+    return max(row_begin - lo, 0), max(hi - (row_end - 1), 0)
+
+
+def plan_slab(cols: np.ndarray, bounds: list[int], rank: int, mode: str) -> SlabPlan:
+    """Remap global column indices for `mode`.
+
+    halo:      x_ext = [own slab | tail of slab rank-1 (halo_lo) | head of slab rank+1 (halo_hi)]
+    allgather: x_ext = the whole vector in slab order, every slab padded to the longest one
+    """
+    world = len(bounds) - 1
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    n_local = r1 - r0
+    if mode == "halo":
+        hlo, hhi = needed_halo(cols, r0, r1)
+        out = np.empty_like(cols)
+        own = (cols >= r0) & (cols < r1)
+        below = cols < r0
+        above = cols >= r1
+        out[own] = cols[own] - r0
+        out[below] = n_local + (cols[below] - (r0 - hlo))
+        out[above] = n_local + hlo + (cols[above] - r1)
+        return SlabPlan("halo", n_local, n_local + hlo + hhi, r0, hlo, hhi, out)
+    pad = max(bounds[p + 1] - bounds[p] for p in range(world))
+    owner = np.searchsorted(np.asarray(bounds[1:]), cols, side="right")
+    out = owner * pad + (cols - np.asarray(bounds)[owner])
+    return SlabPlan("allgather", n_local, pad * world, r0, 0, 0, out.astype(np.int64))
+
+
+def halo_feasible(hlo: int, hhi: int, bounds: list[int], rank: int) -> bool:
+    """The halo form needs every remote column to live in an adjacent slab."""
+    world = len(bounds) - 1
+    if hlo and (rank == 0 or hlo > bounds[rank] - bounds[rank - 1]):
+        return False
+    if hhi and (rank == world - 1 or hhi > bounds[rank + 2] - bounds[rank + 1]):
+        return False
+    return True
+
+
+class Comm:
+    """torch.distributed on tensors as they are (nccl on GPU tensors, gloo on CPU tensors)."""
+
+    def __init__(self, dist, torch, device="cpu"):
+        self.dist, self.torch, self.device = dist, torch, device
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def _ctl_device(self):
+        """Where small control tensors live: what the backend can move."""
+        return self.device
+
+    def all_gather_ints(self, values):
+        """Every rank's list of ints (setup only)."""
+        if self.world == 1:
+            return [list(values)]
+        t = self.torch.tensor(list(values), dtype=self.torch.int64, device=self._ctl_device())
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [[int(x) for x in o.cpu()] for o in out]
+
+    def all_agree(self, flag: bool) -> bool:
+        """True only if `flag` is true on every rank (setup only)."""
+        return all(v[0] for v in self.all_gather_ints([1 if flag else 0]))
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def all_gather_into(self, out, inp):
+        if self.world > 1:
+            self.dist.all_gather_into_tensor(out, inp)
+        else:
+            out.copy_(inp)
+
+    def neighbour_exchange(self, send_lo, recv_lo, send_hi, recv_hi):
+        """send_lo goes to rank-1, send_hi to rank+1; recv_lo comes from rank-1, recv_hi from rank+1.
+        Any of them may be None."""
+        ops = []
+        d = self.dist
+        if send_lo is not None:
+            ops.append(d.P2POp(d.isend, send_lo, self.rank - 1))
+        if recv_hi is not None:
+            ops.append(d.P2POp(d.irecv, recv_hi, self.rank + 1))
+        if send_hi is not None:
+            ops.append(d.P2POp(d.isend, send_hi, self.rank + 1))
+        if recv_lo is not None:
+            ops.append(d.P2POp(d.irecv, recv_lo, self.rank - 1))
+        if ops:
+            for r in d.batch_isend_irecv(ops):
+                r.wait()
+
+
+class StagedComm(Comm):
+    """Same interface, but every payload goes through host memory and the gloo
+    backend.  Only for rehearsing several ranks on ONE GPU (RCCL refuses two
+    ranks on one device); never used by bench.py."""
+
+    def _stage(self, t):
+        return t.detach().to("cpu")
+
+    def _ctl_device(self):
+        return "cpu"
+
+    def all_reduce_sum(self, t):
+        if self.world > 1:
+            c = self._stage(t)
+            self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
+            t.copy_(c)
+
+    def all_gather_into(self, out, inp):
+        if self.world > 1:
+            c_out = self.torch.empty(out.shape, dtype=out.dtype)
+            self.dist.all_gather_into_tensor(c_out, self._stage(inp).contiguous())
+            out.copy_(c_out)
+        else:
+            out.copy_(inp)
+
+    def neighbour_exchange(self, send_lo, recv_lo, send_hi, recv_hi):
+        d = self.dist
+        bufs = {}
+        reqs = []
+        if send_lo is not None:
+            reqs.append(d.isend(self._stage(send_lo).contiguous(), self.rank - 1))
+        if send_hi is not None:
+            reqs.append(d.isend(self._stage(send_hi).contiguous(), self.rank + 1))
+        if recv_hi is not None:
+            bufs["hi"] = self.torch.empty(recv_hi.shape, dtype=recv_hi.dtype)
+            reqs.append(d.irecv(bufs["hi"], self.rank + 1))
+        if recv_lo is not None:
+            bufs["lo"] = self.torch.empty(recv_lo.shape, dtype=recv_lo.dtype)
+            reqs.append(d.irecv(bufs["lo"], self.rank - 1))
+        for r in reqs:
+            r.wait()
+        if recv_hi is not None:
+            recv_hi.copy_(bufs["hi"])
+        if recv_lo is not None:
+            recv_lo.copy_(bufs["lo"])
+
+
+class DistLanczos:
+    """One rank's share of a row-partitioned Lanczos run.
+
+    `make_engine(plan, x_ext, max_iter)` returns an object with the phase
+    interface of lanczos_amd.Engine (phase_spmv, phase_recur, phase_dots,
+    phase_update, phase_scale, export_vector, set_start_scaled, history) whose
+    phase methods take a torch tensor `red` living where the engine computes.
+    """
+
+    def __init__(self, comm: Comm, torch, device, plan: SlabPlan, bounds, max_iter: int, make_engine,
+                 reorth: str = "full"):
+        self.comm, self.torch, self.device = comm, torch, device
+        self.plan, self.bounds, self.max_iter, self.reorth = plan, bounds, max_iter, reorth
+        self.rank, self.world = comm.rank, comm.world
+        self.x_ext = torch.zeros(plan.n_ext, dtype=torch.float64, device=device)
+        self.red = torch.zeros(max(max_iter, 8), dtype=torch.float64, device=device)
+        self.engine = make_engine(plan, self.x_ext, max_iter)
+        self.k = 0
+        if plan.mode == "halo":
+            # what the neighbours need from this slab
+            need = comm.all_gather_ints([plan.halo_lo, plan.halo_hi])
+            self.send_lo = need[self.rank - 1][1] if self.rank > 0 else 0               # head, for rank-1
+            self.send_hi = need[self.rank + 1][0] if self.rank < self.world - 1 else 0  # tail, for rank+1
+            assert self.send_lo <= plan.n_local and self.send_hi <= plan.n_local
+        else:
+            self.pad = plan.n_ext // self.world
+
+    # -- start vector ---------------------------------------------------------
+    def set_start(self, v0_local: np.ndarray):
+        """v0_local: this slab's entries of the global start vector; normalised globally."""
+        t = self.torch.tensor([float(np.dot(v0_local, v0_local))], dtype=self.torch.float64, device=self.device)
+        self.comm.all_reduce_sum(t)
+        norm2 = float(t.cpu()[0])
+        self.engine.set_start_scaled(v0_local, 1.0 / np.sqrt(norm2))
+        self.k = 0
+
+    # -- the vector exchange --------------------------------------------------
+    def exchange(self):
+        p, n = self.plan, self.plan.n_local
+        if p.mode == "allgather":
+            mine = self.x_ext[self.rank * self.pad: self.rank * self.pad + n]
+            self.engine.export_vector(self.k, mine)
+            if self.world > 1:
+                self.comm.all_gather_into(self.x_ext, self.x_ext[self.rank * self.pad:(self.rank + 1) * self.pad])
+            return
+        self.engine.export_vector(self.k, self.x_ext[:n])
+        if self.world == 1:
+            return
+        send_lo = self.x_ext[:self.send_lo] if self.send_lo else None
+        send_hi = self.x_ext[n - self.send_hi:n] if self.send_hi else None
+        recv_lo = self.x_ext[n:n + p.halo_lo] if p.halo_lo else None
+        recv_hi = self.x_ext[n + p.halo_lo:n + p.halo_lo + p.halo_hi] if p.halo_hi else None
+        self.comm.neighbour_exchange(send_lo, recv_lo, send_hi, recv_hi)
+
+    # -- one iteration (reference src/lanczos.c:109-190, split at the reductions) --
+    def step(self):
+        e, red = self.engine, self.red
+        self.exchange()
+        e.phase_spmv(red)
+        self.comm.all_reduce_sum(red[:1])                 # alpha
+        n_red, is_norm = e.phase_recur(red)
+        self.comm.all_reduce_sum(red[:n_red])             # reorth coefficients, or beta^2
+        if not is_norm:
+            e.phase_update(red)
+            if self.reorth == "full2":
+                n2 = e.phase_dots(red)
+                self.comm.all_reduce_sum(red[:n2])
+                e.phase_update(red)
+            self.comm.all_reduce_sum(red[:1])             # beta^2
+        e.phase_scale(red)
+        self.k += 1
+
+    def run(self, steps: int):
+        for _ in range(steps):
+            self.step()
+
+    def history(self):
+        return self.engine.history(self.k)
+
+
+# ---------------------------------------------------------------------------
+# GPU glue
+# ---------------------------------------------------------------------------
+class _GpuPhaseEngine:
+    """lanczos_amd.Engine with tensors in place of raw device addresses."""
+
+    def __init__(self, la, a_local, plan: SlabPlan, x_ext, max_iter, reorth, n_global, stream, spmv="auto",
+                 profile=False):
+        self.la = la
+        mat = la.CrsMatrix(a_local.values, plan.column_index, a_local.row_head_indexes)
+        self.e = la.Engine(mat, max_iter, reorth=reorth, spmv=spmv, profile=profile, stream=stream,
+                           n_global=n_global, row_begin=plan.row_begin, n_ext=plan.n_ext, x_ext=x_ext.data_ptr())
+
+    def set_start_scaled(self, v0, scale):
+        self.e.set_start_scaled(v0, scale)
+
+    def export_vector(self, k, dst):
+        self.e.export_vector(k, dst.data_ptr())
+
+    def phase_spmv(self, red):
+        self.e.phase_spmv(red.data_ptr())
+
+    def phase_recur(self, red):
+        return self.e.phase_recur(red.data_ptr())
+
+    def phase_dots(self, red):
+        return self.e.phase_dots(red.data_ptr())
+
+    def phase_update(self, red):
+        self.e.phase_update(red.data_ptr())
+
+    def phase_scale(self, red):
+        self.e.phase_scale(red.data_ptr())
+
+    def history(self, count):
+        return self.e.history(count)
+
+
+def choose_mode(cols, bounds, rank, comm, want="auto"):
+    """All ranks must use the same exchange form: halo only if every rank can."""
+    if want in ("halo", "allgather"):
+        return want
+    hlo, hhi = needed_halo(cols, bounds[rank], bounds[rank + 1])
+    n_local = bounds[rank + 1] - bounds[rank]
+    ok = halo_feasible(hlo, hhi, bounds, rank) and (hlo + hhi) <= n_local // 2 + 1
+    return "halo" if comm.all_agree(ok) else "allgather"
+
+
+def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mode="auto", spmv="auto",
+                   profile=False):
+    """a_local: this rank's slab as a CrsMatrix with GLOBAL column indices."""
+    rank = comm.rank
+    device = torch.device("cuda", torch.cuda.current_device())
+    mode = choose_mode(a_local.column_index, bounds, rank, comm, mode)
+    plan = plan_slab(a_local.column_index, bounds, rank, mode)
+    # One side stream carries the engine's kernels AND torch's collectives/copies, so
+    # they are ordered without host syncs.  It must not be the legacy default stream:
+    # its handle is 0, which the C ABI reads as "create a private stream".
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    stream = side.cuda_stream
+    assert stream != 0
+    n_global = bounds[-1]
+
+    def make_engine(plan_, x_ext, max_iter_):
+        return _GpuPhaseEngine(la, a_local, plan_, x_ext, max_iter_, reorth, n_global, stream, spmv, profile)
+
+    runner = DistLanczos(comm, torch, device, plan, bounds, max_iter, make_engine, reorth)
+    runner.stream = side  # keeps the stream alive as long as the engine launches on it
+    return runner
+
+
+def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
+    """bench.py for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
+    import torch
+    import torch.distributed as dist
+
+    import lanczos_amd as la
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    comm = Comm(dist, torch, torch.device("cuda", local_rank))
+    d, N = workloads[args.workload]
+    n = N ** d
+    bounds = partition_rows(n, world)
+    a_local = la.synth_laplacian_rows(d, N, bounds[rank], bounds[rank + 1])
+    nnz_t = torch.tensor([float(a_local.length)], dtype=torch.float64, device="cuda")
+    dist.all_reduce(nnz_t)
+    nnz = int(nnz_t.item())
+    K, W = args.steps, args.warmup
+    runner = build_gpu_rank(la, torch, comm, a_local, bounds, max(K, W) + 1, reorth=args.reorth, spmv=args.spmv,
+                            profile=True)
+    v0 = la.gaussian_fill(123456789, bounds[rank], bounds[rank + 1] - bounds[rank])
+    runner.set_start(v0)
+    runner.run(W)
+    runner.set_start(v0)
+    runner.engine.e.profile_reset()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    runner.run(K)
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+    alpha, beta = runner.history()
+    prof = runner.engine.e.profile()
+    out = None
+    if rank == 0:
+        bytes_ = algorithmic_bytes(n, nnz)
+        ritz = la.ritz_values(alpha, beta, K, 4)
+        name = max(prof, key=lambda k_: prof[k_]["ms"])
+        p = prof[name]
+        achieved = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+        out = {
+            "metric": "Lanczos iters/sec",
+            "value": K / dt,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": dt / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), {K} Lanczos steps from a fixed "
+                            f"N(0,1) start vector, reorth={args.reorth}, row-partitioned over {world} GPUs "
+                            f"({runner.plan.mode} exchange + 3 all-reduces per step)",
+                "reorth": args.reorth,
+                "exchange": runner.plan.mode,
+                "parallelism": f"row-partition x{world}",
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": name, "achieved": achieved, "peak": hbm_peak, "unit": "GB/s",
+                "frac": achieved / hbm_peak, "traffic": None, "launches": p["launches"],
+                "note": "rank 0's slab; per-GPU figure",
+            },
+            "algorithmic_bytes_per_iter_no_reorth": bytes_["iter"],
+            "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
+            "ritz_lowest4": [float(x) for x in ritz],
+        }
+    dist.barrier()
+    dist.destroy_process_group()
+    return out

@@ -30,7 +30,7 @@ static int alloc_crs(Mat_Crs *out, size_t n, size_t nnz) {
     return 0;
 }
 
-int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out) {
+int lanczos_synth_laplacian_rows(int d, int64_t N, int64_t row_begin, int64_t row_end, Mat_Crs *out) {
     if (!out || d < 1 || d > 3 || N < 1) return 1;
     memset(out, 0, sizeof *out);
     int64_t n = 1;
@@ -38,34 +38,37 @@ int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out) {
         if (n > INT32_MAX / N) return 1;
         n *= N;
     }
+    if (row_begin < 0 || row_end > n || row_begin >= row_end) return 1;
+    const int64_t rows = row_end - row_begin;
     const int64_t stride[3] = {1, N, N * N};
-    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rows + 1));
     if (!head) return 1;
     out->row_head_indexes = head;
     /* row lengths are known in closed form: 1 + number of in-range neighbours */
     head[0] = 0;
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t r = 0; r < rows; r++) {
         int cnt = 1;
-        int64_t rem = i;
+        int64_t rem = row_begin + r;
         for (int a = 0; a < d; a++) {
             const int64_t c = rem % N;
             rem /= N;
             cnt += (c > 0) + (c < N - 1);
         }
-        head[i + 1] = cnt;
+        head[r + 1] = cnt;
     }
-    for (int64_t i = 0; i < n; i++) head[i + 1] += head[i];
-    if (alloc_crs(out, (size_t)n, (size_t)head[n])) return 1;
+    for (int64_t r = 0; r < rows; r++) head[r + 1] += head[r];
+    if (alloc_crs(out, (size_t)rows, (size_t)head[rows])) return 1;
 #pragma omp parallel for schedule(static)
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t r = 0; r < rows; r++) {
+        const int64_t i = row_begin + r;
         int64_t coord[3] = {0, 0, 0};
         int64_t rem = i;
         for (int a = 0; a < d; a++) {
             coord[a] = rem % N;
             rem /= N;
         }
-        int64_t p = head[i];
+        int64_t p = head[r];
         for (int a = d - 1; a >= 0; a--) /* lower neighbours, ascending column */
             if (coord[a] > 0) {
                 out->column_index[p] = i - stride[a];
@@ -80,6 +83,16 @@ int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out) {
             }
     }
     return 0;
+}
+
+int lanczos_synth_laplacian(int d, int64_t N, Mat_Crs *out) {
+    if (d < 1 || d > 3 || N < 1) return 1;
+    int64_t n = 1;
+    for (int i = 0; i < d; i++) {
+        if (n > INT32_MAX / N) return 1;
+        n *= N;
+    }
+    return lanczos_synth_laplacian_rows(d, N, 0, n, out);
 }
 
 static inline uint64_t mix64(uint64_t z) {

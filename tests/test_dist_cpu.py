@@ -1,0 +1,169 @@
+"""The row-partitioned path on CPU: partition, column remap, exchange plan and the
+iteration order of lanczos_amd/dist.py, driven with world_size 2 and 3 over the
+gloo backend.  The engine behind the phase interface is a numpy stand-in built
+on the CPU checker (test code only); the result must agree with the
+single-process CPU checker."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from lanczos_amd import dist as ld  # noqa: E402
+
+
+def test_partition_and_plans():
+    assert ld.partition_rows(10, 3) == [0, 3, 6, 10]
+    head = np.array([0, 1, 2, 50, 51, 52, 100])
+    cuts = ld.partition_rows_by_nnz(head, 2)
+    assert cuts[0] == 0 and cuts[-1] == 6 and 2 <= cuts[1] <= 3
+    bounds = [0, 4, 8, 12]
+    cols = np.array([2, 4, 5, 7, 8, 9])           # slab 1 = rows 4..7 reaches 2 below, 2 above
+    assert ld.needed_halo(cols, 4, 8) == (2, 2)
+    p = ld.plan_slab(cols, bounds, 1, "halo")
+    assert (p.n_local, p.n_ext, p.halo_lo, p.halo_hi) == (4, 8, 2, 2)
+    assert list(p.column_index) == [4, 0, 1, 3, 6, 7]
+    q = ld.plan_slab(cols, [0, 4, 8, 13], 1, "allgather")    # slabs padded to 5
+    assert q.n_ext == 15 and list(q.column_index) == [2, 5, 6, 8, 10, 11]
+    assert ld.halo_feasible(2, 2, bounds, 1) and not ld.halo_feasible(5, 0, bounds, 1)
+    assert not ld.halo_feasible(1, 0, bounds, 0)
+
+
+class NumpyPhaseEngine:
+    """Phase interface of lanczos_amd.Engine on numpy; mirrors the engine's semantics."""
+
+    def __init__(self, oracle, a_vals, a_head, plan, x_ext, max_iter, reorth):
+        self.oracle = oracle
+        self.vals, self.head, self.cols = a_vals, a_head, plan.column_index
+        self.n, self.x_ext, self.reorth = plan.n_local, x_ext, reorth
+        self.V = np.zeros((max_iter, self.n))
+        self.k = 0
+        self.beta_prev = 0.0
+        self.alpha_hist, self.beta_hist = [], []
+
+    def set_start_scaled(self, v0, scale):
+        self.V[:] = 0
+        self.V[0] = scale * np.asarray(v0)
+        self.k, self.beta_prev = 0, 0.0
+        self.alpha_hist, self.beta_hist = [], []
+
+    def export_vector(self, k, dst):
+        dst.copy_(torch.from_numpy(self.V[k]))
+
+    def _range(self):
+        return {"none": 0, "cuda_compat": max(self.k - 2, 0)}.get(self.reorth, self.k)
+
+    def phase_spmv(self, red):
+        self.V[self.k + 1] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
+        red[0] = float(self.V[self.k] @ self.V[self.k + 1])
+
+    def phase_recur(self, red):
+        alpha = float(red[0])
+        self.alpha_hist.append(alpha)
+        w = self.V[self.k + 1]
+        prev = self.V[self.k - 1] if self.k > 0 else 0.0
+        w[:] = (w - self.beta_prev * prev) - alpha * self.V[self.k]
+        nl = self._range()
+        if nl == 0:
+            red[0] = float(w @ w)
+            return 1, True
+        red[:nl] = torch.from_numpy(self.V[:nl] @ w)
+        return nl, False
+
+    def phase_dots(self, red):
+        nl = self._range()
+        red[:nl] = torch.from_numpy(self.V[:nl] @ self.V[self.k + 1])
+        return nl
+
+    def phase_update(self, red):
+        nl = self._range()
+        w = self.V[self.k + 1]
+        w -= red[:nl].numpy() @ self.V[:nl]
+        red[0] = float(w @ w)
+
+    def phase_scale(self, red):
+        beta = float(np.sqrt(red[0]))
+        self.V[self.k + 1] /= beta
+        self.beta_prev = beta
+        self.beta_hist.append(beta)
+        self.k += 1
+
+    def history(self, count):
+        return np.array(self.alpha_hist[:count]), np.array(self.beta_hist[:count])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, kind, mode, reorth, steps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import lanczos_amd as la
+    import oracle
+    if kind == "lap2d":
+        full = la.synth_laplacian(2, 30)
+    else:
+        full = la.synth_random_symmetric(700, 6, 11)
+    n = full.dimension
+    bounds = ld.partition_rows(n, world) if kind == "lap2d" else ld.partition_rows_by_nnz(full.row_head_indexes, world)
+    r0, r1 = bounds[rank], bounds[rank + 1]
+    h = full.row_head_indexes
+    vals = full.values[h[r0]:h[r1]].copy()
+    cols = full.column_index[h[r0]:h[r1]].copy()
+    head = (h[r0:r1 + 1] - h[r0]).copy()
+    comm = ld.Comm(dist, torch, "cpu")
+    chosen = ld.choose_mode(cols, bounds, rank, comm, mode)
+    plan = ld.plan_slab(cols, bounds, rank, chosen)
+
+    def make_engine(plan_, x_ext, max_iter):
+        return NumpyPhaseEngine(oracle, vals, head, plan_, x_ext, max_iter, reorth)
+
+    runner = ld.DistLanczos(comm, torch, "cpu", plan, bounds, steps + 1, make_engine, reorth)
+    v0 = la.gaussian_fill(77, 0, n)
+    runner.set_start(v0[r0:r1])
+    runner.run(steps)
+    alpha, beta = runner.history()
+    if rank == 0:
+        ref = oracle.lanczos_crs(full.row_head_indexes, full.column_index, full.values, v0, 4, steps + 1, 0.0,
+                                 {"full2": "full"}.get(reorth, reorth))
+        q.put((chosen, float(np.max(np.abs(alpha - ref.alpha) / np.abs(ref.alpha))),
+               float(np.max(np.abs(beta - ref.beta) / np.abs(ref.beta)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,kind,mode,reorth,expect_mode", [
+    (2, "lap2d", "auto", "full", "halo"),
+    (3, "lap2d", "auto", "none", "halo"),
+    (2, "lap2d", "allgather", "full2", "allgather"),
+    (2, "random", "auto", "full", "allgather"),
+    (3, "random", "auto", "cuda_compat", "allgather"),
+])
+def test_partitioned_run_matches_single_process(world, kind, mode, reorth, expect_mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, mode, reorth, 25, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    chosen, ea, eb = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert chosen == expect_mode
+    # same arithmetic up to summation order across slabs: 1e-12 relative over 25 steps
+    assert ea < 1e-11 and eb < 1e-11, (ea, eb)

@@ -1,0 +1,103 @@
+"""Row-partitioned engines on real kernels.  RCCL refuses two ranks on one GPU,
+so two ranks share cuda:0 here and move their payloads through host memory with
+gloo (lanczos_amd.dist.StagedComm); everything else -- slab upload, remapped
+columns, x_ext gather buffer, phase-level C ABI, iteration order -- is the code
+bench.py runs on several GPUs."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, kind, mode, reorth, steps, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lanczos_amd as la
+    from lanczos_amd import dist as ld
+    torch.cuda.set_device(0)
+    if kind == "lap3d":
+        N = 40
+        n = N ** 3
+        bounds = ld.partition_rows(n, world)
+        a_local = la.synth_laplacian_rows(3, N, bounds[rank], bounds[rank + 1])
+        full = la.synth_laplacian(3, N) if rank == 0 else None
+    else:
+        full = la.synth_random_symmetric(30000, 8, 3)
+        n = full.dimension
+        bounds = ld.partition_rows_by_nnz(full.row_head_indexes, world)
+        h = full.row_head_indexes
+        r0, r1 = bounds[rank], bounds[rank + 1]
+        a_local = la.CrsMatrix(full.values[h[r0]:h[r1]], full.column_index[h[r0]:h[r1]], h[r0:r1 + 1] - h[r0])
+    comm = ld.StagedComm(dist, torch, torch.device("cuda", 0))
+    runner = ld.build_gpu_rank(la, torch, comm, a_local, bounds, steps + 1, reorth=reorth, mode=mode)
+    v0 = la.gaussian_fill(99, 0, n)
+    runner.set_start(v0[bounds[rank]:bounds[rank + 1]])
+    runner.run(steps)
+    alpha, beta = runner.history()
+    if rank == 0:
+        with la.Engine(full, steps + 1, reorth=reorth) as e:
+            e.set_start(v0)
+            a1, b1 = e.run(steps)
+        q.put((runner.plan.mode, float(np.max(np.abs(alpha - a1) / np.abs(a1))),
+               float(np.max(np.abs(beta - b1) / np.abs(b1)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,mode,reorth,expect", [
+    ("lap3d", "auto", "full", "halo"),
+    ("lap3d", "allgather", "none", "allgather"),
+    ("lap3d", "auto", "full2", "halo"),
+    ("random", "auto", "full", "allgather"),
+])
+def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, mode, reorth, 30, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    chosen, ea, eb = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert chosen == expect
+    assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+
+
+def test_bench_distributed_code_path_with_one_rank(gpu):
+    """bench.py's N > 1 path (nccl process group, halo/allgather plumbing) with world size 1."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
+               WORLD_SIZE="1")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--workload", "lap64", "--steps", "40",
+                        "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 40 and out["value"] > 0
+    import lanczos_amd as la
+    a = la.synth_laplacian(3, 64)
+    with la.Engine(a, 41) as e:
+        e.set_start(la.gaussian_fill(123456789, 0, a.dimension))
+        alpha, beta = e.run(40)
+    want = la.ritz_values(alpha, beta, 40, 4)
+    assert np.max(np.abs(np.array(out["ritz_lowest4"]) - want) / want) < 1e-10
