@@ -35,7 +35,11 @@ struct Engine {
     double *d_val = nullptr;
     double *d_V = nullptr;
     double *x_ext = nullptr;  // caller-owned gather buffer (row-partitioned use)
-    double *d_partials = nullptr;
+    double *d_partials = nullptr;    // per-workgroup partials of v_k . w left by the SpMV
+    double *d_norm_parts = nullptr;  // per-workgroup partials of w.w, two halves used alternately
+    int alpha_count = 0, norm_count = 0;
+    bool lazy = false;               // deferred normalisation (three-vector mode on one GPU)
+    int lazy_flushed_k = 0;
     double *d_hpart = nullptr;
     int hstride = 0;
     double *d_red = nullptr;   // [max_iter] reduction results (single-GPU runs)
@@ -54,7 +58,6 @@ struct Engine {
     // iteration state
     int k = 0;
     bool started = false;
-    int recur_parts = 0;
     // profiling
     bool profile = false;
     double prof_ms[LANCZOS_HIP_K_COUNT] = {0};
@@ -80,8 +83,11 @@ struct Engine {
     int check_can_step();
     void reorth_range(int *l0, int *l1) const;
     int launch_spmv(const double *x, const double *xdot, double *y, int *nparts);
-    int launch_finalize(int nparts, double *out);
-    int launch_recur(const double *alpha_p);
+    double *norm_parts(int j) const { return d_norm_parts + (size_t)(j & 1) * (size_t)max_blocks; }
+    int launch_finalize(const double *parts, int nparts, double *out);
+    int launch_recur(const double *alpha_parts, int alpha_cnt);
+    int launch_scale(const double *parts, int cnt);
+    int flush_lazy();
     int launch_dots(int l0, int l1, double *red_out);
     int launch_update(int l0, int l1, const double *h, int *nparts);
     int phase_spmv(double *red);

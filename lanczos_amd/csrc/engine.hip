@@ -221,6 +221,9 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
 
     // ---- small buffers
     HIP_TRY(hipMalloc(&d_partials, sizeof(double) * max_blocks));
+    HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
+    HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
+    lazy = (reorth == LANCZOS_HIP_REORTH_NONE) && x_ext == nullptr;
     hstride = max_blocks;
     const int hl = std::min(max_iter, kMaxDotsSegment);
     HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)hstride * (size_t)hl));
@@ -248,6 +251,7 @@ Engine::~Engine() {
     (void)hipFree(d_rp);
     (void)hipFree(d_V);
     (void)hipFree(d_partials);
+    (void)hipFree(d_norm_parts);
     (void)hipFree(d_hpart);
     (void)hipFree(d_red);
     (void)hipFree(d_scal);
@@ -266,8 +270,9 @@ int Engine::vec_blocks() const {
 }
 
 int Engine::tile_blocks() const {
+    // 4 workgroups per CU: measured best for the basis-streaming kernels
     const int64_t tiles = (ldv / 2) / kTileV2;
-    return (int)std::min<int64_t>(max_blocks, std::max<int64_t>(tiles, 1));
+    return (int)std::min<int64_t>(max_blocks / 2, std::max<int64_t>(tiles, 1));
 }
 
 double Engine::spmv_bytes() const {
@@ -350,9 +355,9 @@ int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *npa
     return 0;
 }
 
-int Engine::launch_finalize(int nparts, double *out) {
+int Engine::launch_finalize(const double *parts, int nparts, double *out) {
     ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * nparts);
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_partials, nparts, out);
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, parts, nparts, out);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -384,7 +389,8 @@ int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
     *nparts = blocks;
     ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (l1 - l0) + 16.0 * (double)n);
     hipLaunchKernelGGL(k_update, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
-                       (double2 *)vec(k + 1), ldv / 2, h, d_partials);
+                       (double2 *)vec(k + 1), ldv / 2, h, norm_parts(k));
+    norm_count = blocks;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -402,7 +408,7 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
     if (normalise) {
         hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)vec(0),
                            (const double2 *)vec(0), ldv / 2, d_partials);
-        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, d_partials, blocks, d_red);
+        hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, (const double *)d_partials, blocks, d_red);
         hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), ldv / 2,
                            (const double *)d_red, 0.0);
     } else {
@@ -413,6 +419,8 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(stream));  // v0 may be pageable host memory
     k = 0;
+    lazy_flushed_k = 0;
+    norm_count = 0;
     started = true;
     return 0;
 }
@@ -441,32 +449,46 @@ void Engine::reorth_range(int *l0, int *l1) const {
 int Engine::phase_spmv(double *red) {
     if (int rc = check_can_step()) return rc;
     const double *x = x_ext ? x_ext : vec(k);
-    int nparts = 0;
-    if (int rc = launch_spmv(x, vec(k), vec(k + 1), &nparts)) return rc;
-    return launch_finalize(nparts, red);
+    if (int rc = launch_spmv(x, vec(k), vec(k + 1), &alpha_count)) return rc;
+    return launch_finalize(d_partials, alpha_count, red);
 }
 
-int Engine::launch_recur(const double *alpha_p) {
+// w <- (w - beta v_{k-1}) - alpha v_k ; alpha = sum of alpha_parts[0..alpha_cnt)
+int Engine::launch_recur(const double *alpha_parts, int alpha_cnt) {
     const int blocks = vec_blocks();
-    recur_parts = blocks;
     ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
     double *ahost = h_hist ? h_hist + 2 * (size_t)k : nullptr;
     hipLaunchKernelGGL(k_recur, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
-                       (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, alpha_p,
-                       (const double *)(d_scal + 1), d_partials, d_alpha + k, ahost);
+                       (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, alpha_parts,
+                       alpha_cnt, (const double *)(d_scal + 1), norm_parts(k), d_alpha + k, ahost);
+    norm_count = blocks;
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// v_{k+1} = w / sqrt(sum of parts[0..cnt)) ; closes iteration k
+int Engine::launch_scale(const double *parts, int cnt) {
+    const int blocks = vec_blocks();
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SCALE, 16.0 * (double)n);
+        double *bhost = h_hist ? h_hist + 2 * (size_t)k + 1 : nullptr;
+        hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1), ldv / 2, parts, cnt,
+                           d_scal + 1, d_beta + k, bhost);
+    }
+    HIP_TRY(hipGetLastError());
+    k += 1;
     return 0;
 }
 
 int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
     // red[0] holds alpha (already reduced over ranks by the caller)
-    if (int rc = launch_recur(red)) return rc;
+    if (int rc = launch_recur(red, 1)) return rc;
     int l0, l1;
     reorth_range(&l0, &l1);
     if (l1 - l0 <= 0) {
         *n_red = 1;
         *is_norm = 1;
-        return launch_finalize(recur_parts, red);
+        return launch_finalize(norm_parts(k), norm_count, red);
     }
     *n_red = l1 - l0;
     *is_norm = 0;
@@ -489,46 +511,62 @@ int Engine::phase_update(double *red) {
     // overwrites red[0] is ordered behind it on the stream
     int nparts = 0;
     if (int rc = launch_update(l0, l1, red, &nparts)) return rc;
-    return launch_finalize(nparts, red);
+    return launch_finalize(norm_parts(k), norm_count, red);
 }
 
-int Engine::phase_scale(double *red) {
-    const int blocks = vec_blocks();
-    {
-        ProfScope ps(this, LANCZOS_HIP_K_SCALE, 16.0 * (double)n);
-        double *bhost = h_hist ? h_hist + 2 * (size_t)k + 1 : nullptr;
-        hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1), ldv / 2,
-                           (const double *)red, d_scal + 1, d_beta + k, bhost);
-    }
+int Engine::phase_scale(double *red) { return launch_scale(red, 1); }
+
+// Record beta of the last deferred-normalisation iteration (its w.w partials are
+// otherwise only consumed by the next iteration's recurrence).
+int Engine::flush_lazy() {
+    if (!lazy || k == 0 || lazy_flushed_k == k) return 0;
+    double *bhost = h_hist ? h_hist + 2 * (size_t)(k - 1) + 1 : nullptr;
+    hipLaunchKernelGGL(k_lazy_flush, dim3(1), dim3(kBlock), 0, stream, (const double *)norm_parts(k - 1), norm_count,
+                       d_beta + (k - 1), bhost);
     HIP_TRY(hipGetLastError());
-    k += 1;
+    lazy_flushed_k = k;
     return 0;
 }
 
-// One whole iteration on a single GPU (no cross-rank reduction in between).
+// One whole iteration on a single GPU: the reductions' last stages are folded
+// into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
-    if (int rc = phase_spmv(d_red)) return rc;
+    if (int rc = check_can_step()) return rc;
+    if (int rc = launch_spmv(vec(k), vec(k), vec(k + 1), &alpha_count)) return rc;
+    if (lazy) {
+        const int blocks = vec_blocks();
+        {
+            ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
+            hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
+                               (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, k,
+                               (const double *)d_partials, alpha_count, (const double *)norm_parts(k - 1), norm_count,
+                               norm_parts(k), d_alpha, d_beta, h_hist);
+        }
+        norm_count = blocks;
+        HIP_TRY(hipGetLastError());
+        k += 1;
+        if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
+        return 0;
+    }
+    if (int rc = launch_recur(d_partials, alpha_count)) return rc;
+    int l0, l1;
+    reorth_range(&l0, &l1);
     if (reorth == LANCZOS_HIP_REORTH_MGS) {
         // exact order of src/lanczos.c:156-167: one basis vector at a time
-        if (int rc = launch_recur(d_red)) return rc;
-        int nparts = recur_parts;
-        for (int l = 0; l < k; ++l) {
-            if (int rc = launch_dots(l, l + 1, d_red + 1)) return rc;
-            if (int rc = launch_update(l, l + 1, d_red + 1, &nparts)) return rc;
+        int nparts = 0;
+        for (int l = l0; l < l1; ++l) {
+            if (int rc = launch_dots(l, l + 1, d_red)) return rc;
+            if (int rc = launch_update(l, l + 1, d_red, &nparts)) return rc;
         }
-        if (int rc = launch_finalize(nparts, d_red)) return rc;
-        return phase_scale(d_red);
-    }
-    int n_red = 0, is_norm = 0;
-    if (int rc = phase_recur(d_red, &n_red, &is_norm)) return rc;
-    if (!is_norm) {
-        if (int rc = phase_update(d_red)) return rc;
-        if (reorth == LANCZOS_HIP_REORTH_FULL2) {
-            if (int rc = phase_dots(d_red, &n_red)) return rc;
-            if (int rc = phase_update(d_red)) return rc;
+    } else if (l1 > l0) {
+        const int passes = reorth == LANCZOS_HIP_REORTH_FULL2 ? 2 : 1;
+        int nparts = 0;
+        for (int p = 0; p < passes; ++p) {
+            if (int rc = launch_dots(l0, l1, d_red)) return rc;
+            if (int rc = launch_update(l0, l1, d_red, &nparts)) return rc;
         }
     }
-    return phase_scale(d_red);
+    return launch_scale(norm_parts(k), norm_count);
 }
 
 int Engine::run(int steps, double *alpha_out, double *beta_out) {
@@ -537,6 +575,7 @@ int Engine::run(int steps, double *alpha_out, double *beta_out) {
     const int k0 = k;
     for (int s = 0; s < steps; ++s)
         if (int rc = enqueue_iteration()) return rc;
+    if (int rc = flush_lazy()) return rc;
     HIP_TRY(hipStreamSynchronize(stream));
     harvest_profile();
     if (alpha_out && steps)
@@ -636,9 +675,15 @@ int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host) {
     if (k < 0 || k > g->k || (g->reorth == LANCZOS_HIP_REORTH_NONE && k + 2 < g->k))
         return lz::fail("lanczos_hip_get_vector: vector %d is not resident (iteration %d)", k, g->k);
     if (hipSetDevice(g->device) != hipSuccess) return lz::fail("lanczos_hip_get_vector: hipSetDevice failed");
+    if (g->flush_lazy() != 0) return EXIT_FAILURE;
     hipError_t st = hipMemcpyAsync(out_host, g->vec(k), sizeof(double) * g->n, hipMemcpyDeviceToHost, g->stream);
+    double beta_prev = 1.0;
+    if (st == hipSuccess && g->lazy && k > 0)
+        st = hipMemcpyAsync(&beta_prev, g->d_beta + (k - 1), sizeof(double), hipMemcpyDeviceToHost, g->stream);
     if (st == hipSuccess) st = hipStreamSynchronize(g->stream);
     if (st != hipSuccess) return lz::fail("lanczos_hip_get_vector: %s", hipGetErrorString(st));
+    if (g->lazy && k > 0)  // the three-vector mode keeps u_k = beta_{k-1} v_k
+        for (int64_t i = 0; i < g->n; ++i) out_host[i] /= beta_prev;
     return 0;
 }
 
@@ -701,6 +746,7 @@ int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_o
     Engine *g = E(e);
     if (count < 0 || count > g->k) return lz::fail("lanczos_hip_history: count=%d of %d", count, g->k);
     if (hipSetDevice(g->device) != hipSuccess) return lz::fail("lanczos_hip_history: hipSetDevice failed");
+    if (g->flush_lazy() != 0) return EXIT_FAILURE;
     hipError_t st = hipStreamSynchronize(g->stream);
     g->harvest_profile();
     if (st == hipSuccess && alpha_out && count)
