@@ -48,22 +48,35 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="lap256", choices=sorted(WORKLOADS))
     ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none"])
-    ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt"])
+    ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
-    ap.add_argument("--cpu-steps", type=int, default=100)
+    ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")
     return ap.parse_args()
 
 
 def cpu_baseline(a, v0, steps: int) -> dict:
     """Time the CPU restatement of the reference loop (oracle/) on a bounded
     sample: the first `steps` iterations of the same matrix and start vector,
-    full reorthogonalisation, all host threads OpenMP gives it."""
+    full reorthogonalisation, all host threads OpenMP gives it.  With steps <= 0
+    a 16-step probe sizes the sample for 10-30 s of CPU work (the reference's
+    cost per step grows linearly with the step index)."""
     import oracle
-    t0 = time.perf_counter()
-    r = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0, "full")
-    wall = time.perf_counter() - t0
+
+    def run(s):
+        t0 = time.perf_counter()
+        r = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, s + 1, 0.0, "full")
+        return r, time.perf_counter() - t0
+
+    if steps <= 0:
+        probe, _ = run(16)
+        per_spmv = probe.timing["spmv"] / 16
+        per_pair = probe.timing["reorthogonalization"] / (16 * 17 / 2)   # ~ sum_k (k + 1) vector passes
+        target, steps = 30.0, 16
+        while steps < 300 and per_spmv * (steps + 8) + per_pair * (steps + 8) * (steps + 9) / 2 < target:
+            steps += 8
+    r, wall = run(steps)
     loop = r.timing["spmv"] + r.timing["diagonalization"] + r.timing["reorthogonalization"]
     return {
         "value": steps / loop,
@@ -73,6 +86,7 @@ def cpu_baseline(a, v0, steps: int) -> dict:
         "sample": f"first {steps} iterations (k < {steps}) of the same matrix and start vector, "
                   f"full reorthogonalisation, threshold 0; loop {loop:.2f} s of {wall:.2f} s wall "
                   f"(spmv {r.timing['spmv']:.2f} s, reorth {r.timing['reorthogonalization']:.2f} s)",
+        "steps": steps,
         "ritz": [float(x) for x in r.eigenvalues],
         "alpha": [float(x) for x in r.alpha[:steps]],
         "beta": [float(x) for x in r.beta[:steps]],
@@ -191,11 +205,20 @@ def single_gpu(args) -> dict:
     }
     if not args.no_cpu_baseline:
         cb = cpu_baseline(a, v0, args.cpu_steps)
-        s = args.cpu_steps
+        s = min(cb["steps"], K)
+        # GPU rate over the same first s iterations (its cost per step also grows with k)
+        eng3 = la.Engine(a, s + 1, reorth=args.reorth, spmv=args.spmv)
+        eng3.set_start(v0)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        eng3.run(s)
+        torch.cuda.synchronize()
+        cb["gpu_same_sample_value"] = s / (time.perf_counter() - t3)
+        eng3.close()
         # the same sample on the GPU, and the agreement of the two alpha/beta sequences
         cb["gpu_same_sample_rel_err"] = {
-            "alpha": float(np.max(np.abs(alpha[:s] - np.array(cb["alpha"])) / np.abs(np.array(cb["alpha"])))),
-            "beta": float(np.max(np.abs(beta[:s] - np.array(cb["beta"])) / np.abs(np.array(cb["beta"])))),
+            "alpha": float(np.max(np.abs(alpha[:s] - np.array(cb["alpha"][:s])) / np.abs(np.array(cb["alpha"][:s])))),
+            "beta": float(np.max(np.abs(beta[:s] - np.array(cb["beta"][:s])) / np.abs(np.array(cb["beta"][:s])))),
         }
         del cb["alpha"], cb["beta"], cb["ritz"]
         out["cpu_baseline"] = cb

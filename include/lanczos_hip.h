@@ -109,8 +109,10 @@ enum {
     LANCZOS_HIP_SPMV_AUTO = 0,
     LANCZOS_HIP_SPMV_VECTOR = 1, /* 2^g lanes per row, g chosen from mean row length */
     LANCZOS_HIP_SPMV_STREAM = 2, /* one wavefront per group of 64 rows, nnz streamed through LDS */
-    LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups (the default) */
-    LANCZOS_HIP_SPMV_PIPE_NT = 4 /* pipe form with non-temporal col/val loads */
+    LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups */
+    LANCZOS_HIP_SPMV_PIPE_NT = 4, /* pipe form with non-temporal col/val loads */
+    LANCZOS_HIP_SPMV_ROWS = 5    /* pipe form whose gathers run row-wise (coalesced for stencil-like
+                                    matrices); needs every 64-row group to hold <= 512 entries */
 };
 
 /* Kernel classes for lanczos_hip_profile(). */
@@ -207,7 +209,9 @@ int lanczos_hip_profile(const lanczos_hip_engine *e, int kernel_class, double *m
                         int64_t *launches, double *bytes);
 void lanczos_hip_profile_reset(lanczos_hip_engine *e);
 
-/* Name of the SpMV kernel variant the engine selected ("vector8", "stream", ...). */
+/* Name of the SpMV kernel variant the engine selected ("rows64", "pipe16", "vector8", ...).
+ * LANCZOS_HIP_SPMV_AUTO picks "rows" when every 64-row group fits one tile and, on a
+ * sample of rows, most neighbouring rows hold neighbouring columns; "pipe" otherwise. */
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
 
 /*

@@ -141,7 +141,7 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
     n_global = opt.n_global ? opt.n_global : n;
     row_begin = opt.row_begin;
     if (reorth < 0 || reorth > LANCZOS_HIP_REORTH_FULL2) return fail("lanczos_hip_create: bad reorth mode %d", reorth);
-    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_PIPE_NT)
+    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_ROWS)
         return fail("lanczos_hip_create: bad spmv_kernel %d", opt.spmv_kernel);
     if (opt.device >= 0) {
         HIP_TRY(hipSetDevice(opt.device));
@@ -197,14 +197,37 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
     // ---- SpMV variant
     const double mean = (double)nnz / (double)n;
     spmv_kind = opt.spmv_kernel;
-    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) spmv_kind = LANCZOS_HIP_SPMV_PIPE;
+    // largest nnz span of a 64-row group, and how often neighbouring rows hold
+    // neighbouring columns (sampled): what the row-wise gather form needs / likes
+    int64_t max_span = 0;
+    for (int64_t g = 0; g < n; g += 64) max_span = std::max(max_span, rp[std::min(g + 64, n)] - rp[g]);
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kTile)
+        return fail("lanczos_hip_create: the rows SpMV needs every 64-row group to hold <= %d entries (max %lld)",
+                    kTile, (long long)max_span);
+    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) {
+        spmv_kind = LANCZOS_HIP_SPMV_PIPE;
+        if (max_span <= kTile && n >= 2) {
+            int64_t pairs = 0, alike = 0;
+            const int64_t stride = std::max<int64_t>(1, (n - 1) / 4096);
+            for (int64_t r = 0; r + 1 < n; r += stride) {
+                const int64_t len = std::min(rp[r + 1] - rp[r], rp[r + 2] - rp[r + 1]);
+                for (int64_t j = 0; j < len; ++j) {
+                    pairs++;
+                    alike += (ci[rp[r + 1] + j] == ci[rp[r] + j] + 1);
+                }
+            }
+            if (pairs > 0 && 2 * alike > pairs) spmv_kind = LANCZOS_HIP_SPMV_ROWS;
+        }
+    }
     group = pick_group(mean);
     // rows per wavefront group of the pipe kernel: the largest of 64,32,16,8,4,1
     // whose typical nnz span still fits one tile
     log2r = 6;
     while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
     if (log2r == 1) log2r = 0;
-    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
+        snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
+    else if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)
         snprintf(spmv_name, sizeof(spmv_name), "pipe%d%s%s", 1 << log2r,
                  spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT ? "_nt" : "", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_STREAM)
@@ -282,6 +305,15 @@ double Engine::spmv_bytes() const {
 template <typename RP>
 static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double *y, int *nparts) {
     const RP *rp = (const RP *)e->d_rp;
+    if (e->spmv_kind == LANCZOS_HIP_SPMV_ROWS) {
+        const int64_t groups = (e->n + 63) / 64;
+        const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+        int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
+        *nparts = blocks;
+        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp, e->d_col,
+                           e->d_val, x, xdot, y, e->d_partials);
+        return;
+    }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_PIPE || e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {
         const int lr = e->log2r;
         const int64_t groups = (e->n + (1 << lr) - 1) >> lr;

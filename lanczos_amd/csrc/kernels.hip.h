@@ -353,6 +353,148 @@ k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
 }
 
 // ---------------------------------------------------------------------------
+// SpMV, "rows" form: the pipe form with the gathers issued row-wise
+// ---------------------------------------------------------------------------
+//
+// In the stream/pipe forms lane l gathers x for the l-th entry of the group's
+// span, so neighbouring lanes read unrelated addresses and the texture
+// addresser spends one cycle per lane on every gather: profiling the pipe form
+// on the 7-point Laplacian shows it ~93 % busy, i.e. that kernel is bound by the
+// gather issue rate, not by HBM.  Here the col/val tile is still loaded
+// coalesced in span order, but it is parked in LDS and lane r then walks ITS OWN
+// row: the j-th gather of the wavefront reads x[col(row r, entry j)] for
+// r = 0..63.  For stencil-like matrices consecutive rows hold consecutive
+// columns, so those 64 addresses are contiguous and the gather costs what a
+// coalesced load costs.  Each lane sums its row left to right (the order of
+// src/crs.c:172-175) and no product is staged in LDS.
+//
+// Used when every 64-row group's span fits one tile (checked on the host);
+// rows longer than kRowChunk entries loop over chunks.
+constexpr int kRowChunk = 8;
+
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+            const double *__restrict__ val, const double *__restrict__ x,
+            const double *__restrict__ xdot, double *__restrict__ y,
+            double *__restrict__ partials) {
+    __shared__ double lds_v[kWavesPerBlock][kTile];
+    __shared__ int32_t lds_c[kWavesPerBlock][kTile];
+    __shared__ double red[kWavesPerBlock];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t groups = (n + 63) >> 6;
+    const int64_t total = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (total + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > total) c_end = total;
+    const int64_t c0 = xcd * per_xcd + slot;
+    const int64_t count = c0 < c_end ? (c_end - c0 + slots - 1) / slots : 0;
+    double *myv = lds_v[wave];
+    int32_t *myc = lds_c[wave];
+    double acc = 0.0;
+
+    auto row_of = [&](int64_t i) -> int64_t {
+        const int64_t r = (((c0 + i * slots) * kWavesPerBlock + wave) << 6) + lane;
+        return r < n ? r : n;
+    };
+    auto offsets = [&](int64_t r, RP &lo, RP &hi) {
+        lo = rp[r];
+        hi = rp[r < n ? r + 1 : n];
+    };
+    auto issue_colval = [&](RP s_lo, RP s_hi, int32_t (&cj)[kTileU], double (&vj)[kTileU]) {
+        const RP last = s_hi > s_lo ? s_hi - 1 : (s_lo > 0 ? s_lo - 1 : 0);
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            RP j = s_lo + u * 64 + lane;
+            j = j < last ? j : last;
+            cj[u] = col[j];
+        }
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            RP j = s_lo + u * 64 + lane;
+            j = j < last ? j : last;
+            vj[u] = val[j];
+        }
+    };
+    auto step = [&](int64_t i, int32_t (&c_c)[kTileU], double (&v_c)[kTileU], int32_t (&c_n)[kTileU],
+                    double (&v_n)[kTileU], RP &lo_c, RP &hi_c, const RP &lo_n, const RP &hi_n) {
+        const int64_t row = row_of(i);
+        const RP my_lo = lo_c, my_hi = hi_c;
+        const RP span_lo = __shfl(my_lo, 0);
+        const int off = (int)(my_lo - span_lo);   // this row's first entry inside the tile
+        const int len = (int)(my_hi - my_lo);
+        const int32_t safe_col = (int32_t)(row < n ? row : n - 1);
+        // (a) park this group's tile in LDS
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            myc[u * 64 + lane] = c_c[u];
+            myv[u * 64 + lane] = v_c[u];
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (b) row-wise gathers of the first chunk
+        int32_t cr[kRowChunk];
+        double xr[kRowChunk];
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) cr[j] = j < len ? myc[off + j] : safe_col;
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) xr[j] = x[cr[j]];
+        const double xd = xdot[row < n ? row : n - 1];
+        // (c) offsets of group i+2, col/val of group i+1 (behind the gathers in the queue)
+        offsets(row_of(i + 2 < count ? i + 2 : count - 1), lo_c, hi_c);
+        issue_colval(__shfl(lo_n, 0), __shfl(hi_n, 63), c_n, v_n);
+        // (d) the row sum, left to right
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) {
+            const double v = j < len ? myv[off + j] : 0.0;
+            sum += v * xr[j];
+        }
+        // rows longer than one chunk (wave-uniform trip count)
+        int maxlen = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(maxlen, o);
+            maxlen = other > maxlen ? other : maxlen;
+        }
+        for (int j0 = kRowChunk; j0 < maxlen; j0 += kRowChunk) {
+#pragma unroll
+            for (int j = 0; j < kRowChunk; ++j) {
+                const bool in = j0 + j < len;
+                const double v = in ? myv[off + j0 + j] : 0.0;
+                const int32_t c = in ? myc[off + j0 + j] : safe_col;
+                sum += v * x[c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row < n) {
+            y[row] = sum;
+            acc += sum * xd;
+        }
+    };
+
+    if (count > 0) {
+        RP loA, hiA, loB, hiB;
+        offsets(row_of(0), loA, hiA);
+        offsets(row_of(count > 1 ? 1 : 0), loB, hiB);
+        int32_t cA[kTileU], cB[kTileU];
+        double vA[kTileU], vB[kTileU];
+        issue_colval(__shfl(loA, 0), __shfl(hiA, 63), cA, vA);
+        int64_t i = 0;
+        for (; i + 1 < count; i += 2) {
+            step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
+            step(i + 1, cB, vB, cA, vA, loB, hiB, loA, hiA);
+        }
+        if (i < count) step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// ---------------------------------------------------------------------------
 // Small finaliser: out[0] = sum(partials[0..count)) in a fixed order
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -487,8 +629,8 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
     if (k > 0) {
 #pragma unroll 4
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = w[i];
-            const double2 p = uprev[i], q = uk[i];
+            double2 a = ld_stream(w + i);
+            const double2 p = ld_stream(uprev + i), q = ld_stream(uk + i);
             a.x = (s_k * a.x - c_p * p.x) - c_k * q.x;
             a.y = (s_k * a.y - c_p * p.y) - c_k * q.y;
             w[i] = a;
@@ -497,8 +639,8 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
     } else {
 #pragma unroll 4
         for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = w[i];
-            const double2 q = uk[i];
+            double2 a = ld_stream(w + i);
+            const double2 q = ld_stream(uk + i);
             a.x = a.x - c_k * q.x;
             a.y = a.y - c_k * q.y;
             w[i] = a;

@@ -44,7 +44,7 @@ def spmv_tolerance(a, x):
     return (maxlen + 4) * np.finfo(float).eps * absrow + 1e-300
 
 
-@pytest.mark.parametrize("kind", SPMV_KINDS)
+@pytest.mark.parametrize("kind", SPMV_KINDS + ["rows"])
 def test_spmv_matches_oracle_on_laplacians(gpu, kind):
     for d, N in ((1, 1000), (1, 4097), (2, 67), (3, 20)):
         a = la.synth_laplacian(d, N)
@@ -80,7 +80,29 @@ def test_spmv_zero_matrix_and_auto_kernel(gpu):
         want = oracle.matvec_crs(r.row_head_indexes, r.column_index, r.values, x)
         assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(r, x))
     with la.Engine(la.synth_laplacian(3, 16), 3) as e:
+        assert e.spmv_name == "rows64"           # stencil: neighbouring rows hold neighbouring columns
+    with la.Engine(la.synth_laplacian(3, 16), 3, spmv="pipe") as e:
         assert e.spmv_name == "pipe64"
+
+
+def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
+    # rows of 0..11 entries (more than one 8-entry chunk), unsorted columns, n not a multiple of 64
+    rng = np.random.default_rng(12)
+    n = 1000
+    lens = rng.integers(0, 8, n)
+    lens[rng.integers(0, n, 50)] = 11
+    head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    a = la.CrsMatrix(rng.standard_normal(head[-1]), rng.integers(0, n, head[-1]).astype(np.int64), head)
+    assert int((head[64::64] - head[:-64:64]).max()) <= 512
+    x = rng.standard_normal(n)
+    want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+    with la.Engine(a, 3, spmv="rows") as e:
+        assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(a, x))
+    with la.Engine(a, 3) as e:                       # random columns: the heuristic keeps the pipe form
+        assert e.spmv_name.startswith("pipe")
+    big = irregular_matrix(1000, 3, ((0, 2000),))
+    with pytest.raises(la.LanczosHipError, match="rows SpMV needs"):
+        la.Engine(big, 3, spmv="rows")
 
 
 def test_create_rejects_bad_matrices(gpu):
