@@ -224,6 +224,16 @@ const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
  */
 int lanczos_hip_tridiag_eigs(const double *alpha, const double *beta, int n, int m, double *eig);
 
+/*
+ * Checkpoint / resume (the reference keeps V and T only in memory and frees them at
+ * exit, src/lanczos.c:195-207).  save writes alpha/beta of the iterations done,
+ * every resident basis vector and the pending partial sums to `path`; load
+ * restores them into an engine created for the same matrix, max_iter and reorth
+ * mode, after which lanczos_hip_run continues bit for bit.  Single-GPU engines.
+ */
+int lanczos_hip_checkpoint_save(lanczos_hip_engine *e, const char *path);
+int lanczos_hip_checkpoint_load(lanczos_hip_engine *e, const char *path);
+
 /* Message of the most recent failure on the calling thread ("" if none). */
 const char *lanczos_hip_last_error(void);
 

@@ -98,6 +98,10 @@ _hip.lanczos_hip_phase_dots.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_in
 _hip.lanczos_hip_phase_dots.restype = C.c_int
 _hip.lanczos_hip_export_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 _hip.lanczos_hip_export_vector.restype = C.c_int
+_hip.lanczos_hip_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
+_hip.lanczos_hip_checkpoint_save.restype = C.c_int
+_hip.lanczos_hip_checkpoint_load.argtypes = [C.c_void_p, C.c_char_p]
+_hip.lanczos_hip_checkpoint_load.restype = C.c_int
 _hip.lanczos_hip_local_vector.argtypes = [C.c_void_p, C.c_int]
 _hip.lanczos_hip_local_vector.restype = C.c_void_p
 _hip.lanczos_hip_history.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
@@ -316,6 +320,12 @@ class Engine:
         out = np.empty(self.n)
         _check(_hip.lanczos_hip_get_vector(self._h, k, out.ctypes.data_as(_dp)), "lanczos_hip_get_vector")
         return out
+
+    def checkpoint_save(self, path: str):
+        _check(_hip.lanczos_hip_checkpoint_save(self._h, os.fsencode(path)), "lanczos_hip_checkpoint_save")
+
+    def checkpoint_load(self, path: str):
+        _check(_hip.lanczos_hip_checkpoint_load(self._h, os.fsencode(path)), "lanczos_hip_checkpoint_load")
 
     def profile(self) -> dict:
         out = {}

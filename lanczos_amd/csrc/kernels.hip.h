@@ -73,6 +73,28 @@ __device__ __forceinline__ double block_sum(double v, double *red) {
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Sum of prod[a..b) over each lane's own slice of a tile.  A slice of 64 or more
+// entries (a long row) is summed by the whole wavefront instead of by its one
+// lane, so a hub row of a power-law graph costs the wavefront tile/64 steps per
+// tile rather than tile steps.
+__device__ __forceinline__ double slice_sum(const double *prod, int a, int b, int lane) {
+    double s = 0.0;
+    const bool is_long = (b - a) >= 64;
+    if (!is_long)
+        for (int j = a; j < b; ++j) s += prod[j];
+    unsigned long long todo = __ballot(is_long);
+    while (todo) {  // wave-uniform
+        const int r = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int ra = __shfl(a, r), rb = __shfl(b, r);
+        double p = 0.0;
+        for (int j = ra + lane; j < rb; j += 64) p += prod[j];
+        p = wave_sum(p);
+        if (lane == r) s += p;
+    }
+    return s;
+}
+
 // ---------------------------------------------------------------------------
 // SpMV, "vector" form: G = 2^g lanes cooperate on one row
 // ---------------------------------------------------------------------------
@@ -200,7 +222,9 @@ k_spmv_stream(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
             const RP t1 = (span_hi - t0 > (RP)kTile) ? (RP)(t0 + kTile) : span_hi;
             const RP lo = my_lo > t0 ? my_lo : t0;
             const RP hi = my_hi < t1 ? my_hi : t1;
-            for (RP j = lo; j < hi; ++j) sum += myprod[j - t0];
+            // every lane calls slice_sum (it uses wavefront-wide operations)
+            const int a1 = hi > lo ? (int)(lo - t0) : 0, b1 = hi > lo ? (int)(hi - t0) : 0;
+            sum += slice_sum(myprod, a1, b1, lane);
             __builtin_amdgcn_wave_barrier();
         }
         if (row < n) {
@@ -308,7 +332,8 @@ k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
         {
             const RP t1 = (span_hi - span_lo > (RP)kTile) ? (RP)(span_lo + kTile) : span_hi;
             const RP hi = my_hi < t1 ? my_hi : t1;
-            for (RP j = my_lo; j < hi; ++j) sum += myprod[j - span_lo];
+            const int a0 = (int)(my_lo - span_lo), b0 = hi > my_lo ? (int)(hi - span_lo) : a0;
+            sum = slice_sum(myprod, a0, b0, lane);
         }
         __builtin_amdgcn_wave_barrier();
         // rare: the span does not fit one tile
@@ -324,7 +349,9 @@ k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
             const RP t1 = (span_hi - t0 > (RP)kTile) ? (RP)(t0 + kTile) : span_hi;
             const RP lo = my_lo > t0 ? my_lo : t0;
             const RP hi = my_hi < t1 ? my_hi : t1;
-            for (RP j = lo; j < hi; ++j) sum += myprod[j - t0];
+            // every lane calls slice_sum (it uses wavefront-wide operations)
+            const int a1 = hi > lo ? (int)(lo - t0) : 0, b1 = hi > lo ? (int)(hi - t0) : 0;
+            sum += slice_sum(myprod, a1, b1, lane);
             __builtin_amdgcn_wave_barrier();
         }
         if (row < n) {

@@ -43,3 +43,30 @@ def laplacian_eigs(d, N, count):
 def rel_err(a, b, floor=0.0):
     a, b = np.asarray(a, float), np.asarray(b, float)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor if floor > 0 else 1e-300)))
+
+
+def rmat_laplacian(scale, edge_factor=16, seed=1, abcd=(0.57, 0.19, 0.19, 0.05)):
+    """Graph Laplacian L = D - A of a symmetrised R-MAT graph (self-loops dropped,
+    duplicate edges merged); returns scipy CSR with sorted columns."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = 1 << scale
+    m = edge_factor * n
+    a, b, c, _ = abcd
+    rows = np.zeros(m, np.int64)
+    cols = np.zeros(m, np.int64)
+    for level in range(scale):
+        r = rng.random(m)
+        right = (r >= a) & (r < a + b) | (r >= a + b + c)      # quadrants b and d
+        down = r >= a + b                                      # quadrants c and d
+        rows |= down.astype(np.int64) << level
+        cols |= right.astype(np.int64) << level
+    keep = rows != cols
+    rows, cols = rows[keep], cols[keep]
+    adj = sp.coo_matrix((np.ones(rows.size), (rows, cols)), shape=(n, n)).tocsr()
+    adj = adj + adj.T
+    adj.data[:] = 1.0
+    deg = np.asarray(adj.sum(1)).ravel()
+    lap = (sp.diags(deg) - adj).tocsr()
+    lap.sort_indices()
+    return lap

@@ -13,7 +13,8 @@ import pytest
 
 import lanczos_amd as la
 import oracle
-from matrices import laplacian3d_triplets_by_column, laplacian_eigs, laplacian_triplets_rowwise, rel_err
+from matrices import (laplacian3d_triplets_by_column, laplacian_eigs, laplacian_triplets_rowwise, rel_err,
+                      rmat_laplacian)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -66,6 +67,28 @@ def test_spmv_matches_oracle_on_irregular_rows(gpu, kind):
         with la.Engine(a, 3, spmv=kind) as e:
             got = e.spmv(x)
         assert np.all(np.abs(got - want) <= spmv_tolerance(a, x)), (n, kind)
+
+
+@pytest.mark.parametrize("kind", SPMV_KINDS)
+def test_power_law_graph_laplacian(gpu, kind):
+    """R-MAT scale 16: hub rows of several thousand entries next to rows of one entry."""
+    lap = rmat_laplacian(16)
+    a = crs_from_scipy(lap)
+    lens = np.diff(a.row_head_indexes)
+    assert lens.max() > 2000 and lens.min() <= 2
+    x = np.random.default_rng(3).standard_normal(a.dimension)
+    want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+    v0 = la.gaussian_fill(4, 0, a.dimension)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 31, 0.0)
+    with la.Engine(a, 31, spmv=kind) as e:
+        assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(a, x))
+        e.set_start(v0)
+        alpha, beta = e.run(30)
+    assert rel_err(alpha, o.alpha) < 1e-11 and rel_err(beta, o.beta) < 1e-11
+    # lambda_min of a graph Laplacian is 0: compare Ritz values against ||T||, not against themselves
+    ritz = la.ritz_values(alpha, beta, 30, 4)
+    tnorm = np.abs(alpha).max() + 2 * np.abs(beta).max()
+    assert np.max(np.abs(ritz - o.eigenvalues)) < 1e-10 * tnorm
 
 
 def test_spmv_zero_matrix_and_auto_kernel(gpu):
@@ -233,6 +256,31 @@ def test_engine_limits(gpu):
         e.set_start_seed(1)
         alpha, beta = e.run(50)
         assert np.all(np.isfinite(alpha)) and np.all(beta > 0)
+
+
+@pytest.mark.parametrize("reorth", ["full", "none", "cuda_compat"])
+def test_checkpoint_resume_is_bitwise(gpu, tmp_path, reorth):
+    a = la.synth_laplacian(3, 20)
+    v0 = la.gaussian_fill(8, 0, a.dimension)
+    path = str(tmp_path / "ck.bin")
+    with la.Engine(a, 41, reorth=reorth) as e:
+        e.set_start(v0)
+        alpha, beta = e.run(40)
+    with la.Engine(a, 41, reorth=reorth) as e:
+        e.set_start(v0)
+        a1, b1 = e.run(17)
+        e.checkpoint_save(path)
+    with la.Engine(a, 41, reorth=reorth) as e:
+        e.checkpoint_load(path)
+        assert e.iterations == 17
+        a2, b2 = e.run(23)
+        ah, bh = e.history(40)
+    assert np.concatenate([a1, a2]).tobytes() == alpha.tobytes()
+    assert np.concatenate([b1, b2]).tobytes() == beta.tobytes()
+    assert ah.tobytes() == alpha.tobytes() and bh.tobytes() == beta.tobytes()
+    with la.Engine(la.synth_laplacian(3, 21), 41, reorth=reorth) as e:
+        with pytest.raises(la.LanczosHipError, match="does not fit this engine"):
+            e.checkpoint_load(path)
 
 
 def run_dropin(a, nth, max_iter, threshold, env=None):
