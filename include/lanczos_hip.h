@@ -224,6 +224,27 @@ const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
  */
 int lanczos_hip_tridiag_eigs(const double *alpha, const double *beta, int n, int m, double *eig);
 
+/* Eigenvectors of the same tridiagonal matrix for eigenvalues eig[0..m) (as returned
+ * by lanczos_hip_tridiag_eigs), by inverse iteration on the host; S is m x n
+ * row-major, rows of unit norm with a non-negative first component (the sign rule
+ * of the reference's unused diagonalize_double, src/util.c:100-107). */
+int lanczos_hip_tridiag_eigvecs(const double *alpha, const double *beta, int n, int m, const double *eig,
+                                double *S);
+
+/*
+ * Ritz pairs after `steps` iterations: eig[0..m) = lowest m Ritz values, row i of
+ * vectors_host (m x n row-major, may be NULL) = sum_j s_i[j] v_j with s_i the
+ * eigenvector of the steps x steps tridiagonal matrix, formed on the device from
+ * the resident basis; residual_est[i] (may be NULL) = |beta_{steps-1} s_i[steps-1]|,
+ * the Lanczos bound on ||A y_i - eig_i y_i||.  Both reference solvers accept an
+ * `eigenvectors` argument and never fill it (src/lanczos.c:20,
+ * src/lanczos_cuda.c:284); this is the missing piece, as a separate call because
+ * the reference's driver passes an uninitialised pointer array (src/main.c:20).
+ * Needs the whole basis on one GPU (any reorth mode but none).
+ */
+int lanczos_hip_ritz_vectors(lanczos_hip_engine *e, int steps, int m, double *eig, double *vectors_host,
+                             double *residual_est);
+
 /*
  * Checkpoint / resume (the reference keeps V and T only in memory and frees them at
  * exit, src/lanczos.c:195-207).  save writes alpha/beta of the iterations done,

@@ -98,6 +98,10 @@ _hip.lanczos_hip_phase_dots.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_in
 _hip.lanczos_hip_phase_dots.restype = C.c_int
 _hip.lanczos_hip_export_vector.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 _hip.lanczos_hip_export_vector.restype = C.c_int
+_hip.lanczos_hip_tridiag_eigvecs.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp, _dp]
+_hip.lanczos_hip_tridiag_eigvecs.restype = C.c_int
+_hip.lanczos_hip_ritz_vectors.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp, _dp, _dp]
+_hip.lanczos_hip_ritz_vectors.restype = C.c_int
 _hip.lanczos_hip_checkpoint_save.argtypes = [C.c_void_p, C.c_char_p]
 _hip.lanczos_hip_checkpoint_save.restype = C.c_int
 _hip.lanczos_hip_checkpoint_load.argtypes = [C.c_void_p, C.c_char_p]
@@ -239,6 +243,17 @@ def tridiag_eigs(alpha, beta, n: int, m: int) -> np.ndarray:
     return eig
 
 
+def tridiag_eigvecs(alpha, beta, n: int, eig) -> np.ndarray:
+    alpha, beta, eig = _f64(alpha), _f64(beta if len(beta) else np.zeros(1)), _f64(eig)
+    m = eig.shape[0]
+    S = np.zeros((m, n))
+    rc = _hip.lanczos_hip_tridiag_eigvecs(alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp), n, m,
+                                          eig.ctypes.data_as(_dp), S.ctypes.data_as(_dp))
+    if rc != 0:
+        raise LanczosHipError("lanczos_hip_tridiag_eigvecs failed")
+    return S
+
+
 # ---- solver entry points ----------------------------------------------------
 def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float) -> tuple[int, np.ndarray]:
     """The drop-in entry; returns (status, eigenvalues[nth_eig])."""
@@ -320,6 +335,14 @@ class Engine:
         out = np.empty(self.n)
         _check(_hip.lanczos_hip_get_vector(self._h, k, out.ctypes.data_as(_dp)), "lanczos_hip_get_vector")
         return out
+
+    def ritz_vectors(self, steps: int, m: int):
+        """-> (eig[m], vectors[m, n], residual_est[m]) of the first `steps` iterations."""
+        m = min(m, steps)
+        eig, vecs, res = np.zeros(m), np.zeros((m, self.n)), np.zeros(m)
+        _check(_hip.lanczos_hip_ritz_vectors(self._h, steps, m, eig.ctypes.data_as(_dp), vecs.ctypes.data_as(_dp),
+                                             res.ctypes.data_as(_dp)), "lanczos_hip_ritz_vectors")
+        return eig, vecs, res
 
     def checkpoint_save(self, path: str):
         _check(_hip.lanczos_hip_checkpoint_save(self._h, os.fsencode(path)), "lanczos_hip_checkpoint_save")

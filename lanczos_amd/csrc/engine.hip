@@ -738,6 +738,53 @@ void lanczos_hip_profile_reset(lanczos_hip_engine *e) {
     }
 }
 
+int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *eig, double *vectors_host,
+                             double *residual_est) {
+    if (!eh || !eig || steps < 1 || m < 1) return lz::fail("lanczos_hip_ritz_vectors: bad argument");
+    Engine *e = E(eh);
+    if (e->reorth == LANCZOS_HIP_REORTH_NONE || e->x_ext)
+        return lz::fail("lanczos_hip_ritz_vectors: needs the whole basis resident on one GPU (not reorth=none, not a row slab)");
+    if (steps > e->k) return lz::fail("lanczos_hip_ritz_vectors: only %d iterations done", e->k);
+    if (m > steps) m = steps;
+    if (hipSetDevice(e->device) != hipSuccess) return lz::fail("lanczos_hip_ritz_vectors: hipSetDevice failed");
+    std::vector<double> a((size_t)steps), b((size_t)steps), S((size_t)m * steps);
+    hipError_t st = hipStreamSynchronize(e->stream);
+    if (st == hipSuccess) st = hipMemcpy(a.data(), e->d_alpha, sizeof(double) * steps, hipMemcpyDeviceToHost);
+    if (st == hipSuccess) st = hipMemcpy(b.data(), e->d_beta, sizeof(double) * steps, hipMemcpyDeviceToHost);
+    if (st != hipSuccess) return lz::fail("lanczos_hip_ritz_vectors: %s", hipGetErrorString(st));
+    if (lanczos_hip_tridiag_eigs(a.data(), b.data(), steps, m, eig) != 0 ||
+        lanczos_hip_tridiag_eigvecs(a.data(), b.data(), steps, m, eig, S.data()) != 0)
+        return lz::fail("lanczos_hip_ritz_vectors: tridiagonal eigen-solve failed");
+    if (residual_est)  // |beta_{steps-1} * last component|: the Lanczos bound on ||A y - theta y||
+        for (int i = 0; i < m; ++i) residual_est[i] = fabs(b[(size_t)steps - 1] * S[(size_t)i * steps + steps - 1]);
+    if (!vectors_host) return 0;
+    double *d_y = nullptr, *d_s = nullptr;
+    int rc = 0;
+    if (hipMalloc(&d_y, sizeof(double) * e->ldv) != hipSuccess || hipMalloc(&d_s, sizeof(double) * steps) != hipSuccess)
+        rc = lz::fail("lanczos_hip_ritz_vectors: out of device memory");
+    for (int i = 0; rc == 0 && i < m; ++i) {
+        // y = sum_j S[i][j] V_j, through the update kernel: 0 - sum_j (-S[i][j]) V_j
+        std::vector<double> neg((size_t)steps);
+        for (int j = 0; j < steps; ++j) neg[(size_t)j] = -S[(size_t)i * steps + j];
+        st = hipMemcpyAsync(d_s, neg.data(), sizeof(double) * steps, hipMemcpyHostToDevice, e->stream);
+        if (st == hipSuccess) st = hipMemsetAsync(d_y, 0, sizeof(double) * e->ldv, e->stream);
+        if (st == hipSuccess) {
+            hipLaunchKernelGGL(lz::k_update, dim3(e->tile_blocks()), dim3(lz::kBlock), 0, e->stream,
+                               (const double2 *)e->d_V, e->ldv / 2, 0, steps, (double2 *)d_y, e->ldv / 2,
+                               (const double *)d_s, e->d_partials);
+            st = hipGetLastError();
+        }
+        if (st == hipSuccess)
+            st = hipMemcpyAsync(vectors_host + (size_t)i * e->n, d_y, sizeof(double) * e->n, hipMemcpyDeviceToHost,
+                                e->stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+        if (st != hipSuccess) rc = lz::fail("lanczos_hip_ritz_vectors: %s", hipGetErrorString(st));
+    }
+    (void)hipFree(d_y);
+    (void)hipFree(d_s);
+    return rc;
+}
+
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e) { return e ? E(e)->spmv_name : ""; }
 
 const char *lanczos_hip_last_error(void) { return lz::last_error(); }

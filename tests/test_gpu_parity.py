@@ -243,6 +243,28 @@ def test_converged_values_match_closed_form(gpu):
     assert abs(got[0] - exact[0]) < 1e-10 * exact[0]
 
 
+def test_ritz_vectors_have_small_residuals(gpu):
+    a = la.synth_laplacian(2, 40)
+    with la.Engine(a, 300) as e:
+        e.set_start_seed(3)
+        e.run(299)
+        eig, vecs, est = e.ritz_vectors(299, 3)
+    exact = laplacian_eigs(2, 40, 3)
+    assert abs(eig[0] - exact[0]) < 1e-10 * exact[0]
+    for i in range(3):
+        y = vecs[i]
+        assert abs(np.linalg.norm(y) - 1) < 1e-10
+        r = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, y) - eig[i] * y
+        # the true residual is bounded by the Lanczos estimate (plus rounding)
+        assert np.linalg.norm(r) <= est[i] + 1e-10 * 8
+    assert est[0] < 1e-8                                  # the lowest pair has converged
+    with la.Engine(a, 5, reorth="none") as e:
+        e.set_start_seed(3)
+        e.run(4)
+        with pytest.raises(la.LanczosHipError, match="needs the whole basis"):
+            e.ritz_vectors(4, 1)
+
+
 def test_engine_limits(gpu):
     a = la.synth_laplacian(1, 500)
     with la.Engine(a, 5) as e:

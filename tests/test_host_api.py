@@ -89,6 +89,28 @@ def test_tridiag_eigs_against_mkl_and_oracle(golden_dir):
             assert np.max(np.abs(eig[:iu] - exact) / exact) < 1e-11
 
 
+def test_tridiag_eigvecs():
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 60, 250):
+        alpha = rng.standard_normal(n) * 2 + 4
+        beta = np.abs(rng.standard_normal(max(n - 1, 0))) + 0.05
+        m = min(5, n)
+        eig = la.tridiag_eigs(alpha, beta, n, m)
+        S = la.tridiag_eigvecs(alpha, beta, n, eig)
+        T = np.diag(alpha) + np.diag(beta, 1) + np.diag(beta, -1) if n > 1 else np.array([[alpha[0]]])
+        tnorm = np.abs(T).sum(1).max()
+        for i in range(m):
+            assert abs(np.linalg.norm(S[i]) - 1) < 1e-12 and S[i][0] >= 0
+            assert np.linalg.norm(T @ S[i] - eig[i] * S[i]) < 1e-11 * tnorm
+        assert np.max(np.abs(S @ S.T - np.eye(m))) < 1e-8
+    # a cluster: two almost equal eigenvalues still give two independent vectors
+    alpha = np.array([1.0, 1.0 + 1e-13, 5.0])
+    beta = np.array([1e-14, 1e-14])
+    eig = la.tridiag_eigs(alpha, beta, 3, 2)
+    S = la.tridiag_eigvecs(alpha, beta, 3, eig)
+    assert abs(S[0] @ S[1]) < 1e-6
+
+
 def test_gaussian_fill_is_partition_invariant_and_normal():
     g = la.gaussian_fill(123456789, 0, 200000)
     assert abs(g.mean()) < 0.01 and abs(g.std() - 1) < 0.01
