@@ -161,6 +161,21 @@ int lanczos_hip_create(lanczos_hip_engine **out, int64_t n, int64_t nnz,
                        const int64_t *row_head_indexes, const int64_t *column_index,
                        const double *values, int max_iter, const lanczos_hip_options *opt);
 
+/*
+ * Same engine, built from triplets: the COO -> CRS conversion of convert_from_coo
+ * (src/crs.c:8-153; swap_row_column as there) runs on the device -- the triplets are
+ * uploaded once (16 B each) and the CRS arrays appear where the SpMV reads them,
+ * with rows in input order and duplicates kept, bit for bit what the host build
+ * gives.  An out-of-range index fails with the message of src/crs.c:69-71 (the
+ * host build exits the process there).  Fewer than 2^32 entries.
+ */
+int lanczos_hip_create_from_coo(lanczos_hip_engine **out, const Mat_Coo *mat_coo, int swap_row_column,
+                                int max_iter, const lanczos_hip_options *opt);
+/* Test hook: copy the device CRS back in the layout of Mat_Crs (caller-allocated
+ * row_head_indexes[n+1], column_index[nnz], values[nnz]; the last two may be NULL). */
+int lanczos_hip_download_crs(lanczos_hip_engine *e, int64_t *row_head_indexes, int64_t *column_index,
+                             double *values);
+
 /* Replaces destroy_cusparse_matrix and the cleanup block src/lanczos_cuda.c:720-779. */
 void lanczos_hip_destroy(lanczos_hip_engine *e);
 

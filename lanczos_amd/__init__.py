@@ -61,6 +61,11 @@ _hip.lanczos_hip_crs.restype = C.c_int
 _hip.lanczos_hip_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int,
                                     C.POINTER(Options)]
 _hip.lanczos_hip_create.restype = C.c_int
+_hip.lanczos_hip_create_from_coo.argtypes = [C.POINTER(C.c_void_p), C.POINTER(Mat_Coo), C.c_int, C.c_int,
+                                             C.POINTER(Options)]
+_hip.lanczos_hip_create_from_coo.restype = C.c_int
+_hip.lanczos_hip_download_crs.argtypes = [C.c_void_p, _ip, _ip, _dp]
+_hip.lanczos_hip_download_crs.restype = C.c_int
 _hip.lanczos_hip_destroy.argtypes = [C.c_void_p]
 _hip.lanczos_hip_destroy.restype = None
 _hip.lanczos_hip_set_start.argtypes = [C.c_void_p, _dp]
@@ -279,6 +284,30 @@ class Engine:
                                        a.column_index.ctypes.data_as(_ip),
                                        a.values.ctypes.data_as(_dp), max_iter, C.byref(opt)),
                "lanczos_hip_create")
+
+    @classmethod
+    def from_coo(cls, coo: np.ndarray, dimension: int, swap_row_column: int, max_iter: int, reorth: str = "full",
+                 spmv: str = "auto", profile: bool = False, device: int = -1):
+        """Engine whose CRS arrays are built from the triplets on the device."""
+        self = cls.__new__(cls)
+        self._h = C.c_void_p(None)
+        self.n = dimension
+        self.max_iter = max_iter
+        coo = np.ascontiguousarray(coo, dtype=COO_DTYPE)
+        m = Mat_Coo(C.cast(coo.ctypes.data, C.POINTER(Coo)), coo.shape[0], dimension)
+        opt = Options(C.sizeof(Options), device, None, REORTH[reorth], SPMV[spmv], int(profile), 0, 0, 0, None)
+        _check(_hip.lanczos_hip_create_from_coo(C.byref(self._h), C.byref(m), int(swap_row_column), max_iter,
+                                                C.byref(opt)), "lanczos_hip_create_from_coo")
+        self.nnz = coo.shape[0]
+        return self
+
+    def download_crs(self, nnz: int) -> "CrsMatrix":
+        head = np.zeros(self.n + 1, np.int64)
+        cols = np.zeros(nnz, np.int64)
+        vals = np.zeros(nnz)
+        _check(_hip.lanczos_hip_download_crs(self._h, head.ctypes.data_as(_ip), cols.ctypes.data_as(_ip),
+                                             vals.ctypes.data_as(_dp)), "lanczos_hip_download_crs")
+        return CrsMatrix(vals, cols, head)
 
     def close(self):
         if self._h:

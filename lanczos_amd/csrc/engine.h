@@ -70,8 +70,13 @@ struct Engine {
     static int create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, const int64_t *ci,
                       const double *va, int max_iter, const lanczos_hip_options *opt);
     ~Engine();
-    int init(const lanczos_hip_options &opt, int64_t n, int64_t n_ext, int64_t nnz, const int64_t *rp,
-             const int64_t *ci, const double *va, int max_iter);
+    static int create_from_coo(Engine **out, const Mat_Coo *coo, int swap_row_column, int max_iter,
+                               const lanczos_hip_options *opt);
+    int setup_device(const lanczos_hip_options &opt, int64_t n, int64_t n_ext, int64_t nnz, int max_iter);
+    int upload_crs(const int64_t *rp, const int64_t *ci, const double *va);
+    int build_from_coo(const Coo *coo, int64_t length, int swap_row_column);
+    int choose_spmv(int requested);
+    int alloc_state();
 
     // basis slot of Lanczos vector j (a ring of 3 when nothing older is needed)
     double *vec(int j) const { return d_V + (size_t)(reorth == LANCZOS_HIP_REORTH_NONE ? j % 3 : j) * (size_t)ldv; }

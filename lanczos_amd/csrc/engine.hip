@@ -93,13 +93,22 @@ static int pick_group(double mean_nnz) {
     return g;
 }
 
+static int read_options(lanczos_hip_options *opt, const lanczos_hip_options *opt_in) {
+    memset(opt, 0, sizeof(*opt));
+    opt->device = -1;
+    if (opt_in) memcpy(opt, opt_in, std::min(sizeof(*opt), opt_in->struct_size));
+    if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_FULL2)
+        return fail("lanczos_hip_create: bad reorth mode %d", opt->reorth);
+    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_ROWS)
+        return fail("lanczos_hip_create: bad spmv_kernel %d", opt->spmv_kernel);
+    return 0;
+}
+
 int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, const int64_t *ci,
                    const double *va, int max_iter, const lanczos_hip_options *opt_in) {
     *out = nullptr;
     lanczos_hip_options opt;
-    memset(&opt, 0, sizeof(opt));
-    opt.device = -1;
-    if (opt_in) memcpy(&opt, opt_in, std::min(sizeof(opt), opt_in->struct_size));
+    if (int rc = read_options(&opt, opt_in)) return rc;
     if (n <= 0 || nnz < 0 || !rp || (nnz > 0 && (!ci || !va)))
         return fail("lanczos_hip_create: NULL or empty matrix (n=%lld, nnz=%lld)", (long long)n, (long long)nnz);
     if (n > (int64_t)INT32_MAX)
@@ -120,7 +129,10 @@ int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, cons
     if (bad) return fail("lanczos_hip_create: column index out of range [0, %lld)", (long long)n_ext);
 
     Engine *e = new Engine();
-    int rc = e->init(opt, n, n_ext, nnz, rp, ci, va, max_iter);
+    int rc = e->setup_device(opt, n, n_ext, nnz, max_iter);
+    if (rc == 0) rc = e->upload_crs(rp, ci, va);
+    if (rc == 0) rc = e->choose_spmv(opt.spmv_kernel);
+    if (rc == 0) rc = e->alloc_state();
     if (rc != 0) {
         delete e;
         return rc;
@@ -129,8 +141,7 @@ int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, cons
     return 0;
 }
 
-int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int64_t nnz_,
-                 const int64_t *rp, const int64_t *ci, const double *va, int max_iter_) {
+int Engine::setup_device(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int64_t nnz_, int max_iter_) {
     n = n_;
     n_ext = n_ext_;
     nnz = nnz_;
@@ -140,9 +151,6 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
     x_ext = opt.x_ext;
     n_global = opt.n_global ? opt.n_global : n;
     row_begin = opt.row_begin;
-    if (reorth < 0 || reorth > LANCZOS_HIP_REORTH_FULL2) return fail("lanczos_hip_create: bad reorth mode %d", reorth);
-    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_ROWS)
-        return fail("lanczos_hip_create: bad spmv_kernel %d", opt.spmv_kernel);
     if (opt.device >= 0) {
         HIP_TRY(hipSetDevice(opt.device));
         device = opt.device;
@@ -163,13 +171,16 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         own_stream = true;
     }
-
-    // ---- matrix upload: values as they are, columns narrowed on the device,
-    //      row offsets narrowed on the host when they fit 32 bits
     rp64 = nnz >= ((int64_t)1 << 31);
     HIP_TRY(hipMalloc(&d_val, sizeof(double) * std::max<int64_t>(nnz, 1)));
     HIP_TRY(hipMalloc(&d_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
     HIP_TRY(hipMalloc(&d_rp, (rp64 ? 8 : 4) * (n + 1)));
+    return 0;
+}
+
+// Matrix upload: values as they are, columns narrowed on the device, row offsets
+// narrowed on the host when they fit 32 bits.
+int Engine::upload_crs(const int64_t *rp, const int64_t *ci, const double *va) {
     if (nnz > 0) {
         HIP_TRY(hipMemcpyAsync(d_val, va, sizeof(double) * nnz, hipMemcpyHostToDevice, stream));
         const int64_t chunk = (int64_t)1 << 26;  // 512 MiB of int64 per piece
@@ -193,31 +204,37 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
         HIP_TRY(hipMemcpyAsync(d_rp, rp32.data(), 4 * (n + 1), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    return 0;
+}
 
-    // ---- SpMV variant
+// Pick the SpMV form from the matrix as it sits on the device.
+int Engine::choose_spmv(int requested) {
     const double mean = (double)nnz / (double)n;
-    spmv_kind = opt.spmv_kernel;
+    spmv_kind = requested;
     // largest nnz span of a 64-row group, and how often neighbouring rows hold
     // neighbouring columns (sampled): what the row-wise gather form needs / likes
-    int64_t max_span = 0;
-    for (int64_t g = 0; g < n; g += 64) max_span = std::max(max_span, rp[std::min(g + 64, n)] - rp[g]);
+    unsigned long long *d_stats = nullptr, stats[3] = {0, 0, 0};
+    HIP_TRY(hipMalloc(&d_stats, sizeof(stats)));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(stats), stream));
+    const int64_t stride = std::max<int64_t>(1, (n - 1) / 4096);
+    const int blocks = (int)std::min<int64_t>(max_blocks, ((n + 63) / 64 + kBlock - 1) / kBlock);
+    if (rp64)
+        hipLaunchKernelGGL((k_row_stats<int64_t>), dim3(blocks), dim3(kBlock), 0, stream, n, (const int64_t *)d_rp,
+                           d_col, stride, d_stats);
+    else
+        hipLaunchKernelGGL((k_row_stats<int32_t>), dim3(blocks), dim3(kBlock), 0, stream, n, (const int32_t *)d_rp,
+                           d_col, stride, d_stats);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    HIP_TRY(hipFree(d_stats));
+    const int64_t max_span = (int64_t)stats[0];
     if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kTile)
         return fail("lanczos_hip_create: the rows SpMV needs every 64-row group to hold <= %d entries (max %lld)",
                     kTile, (long long)max_span);
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) {
         spmv_kind = LANCZOS_HIP_SPMV_PIPE;
-        if (max_span <= kTile && n >= 2) {
-            int64_t pairs = 0, alike = 0;
-            const int64_t stride = std::max<int64_t>(1, (n - 1) / 4096);
-            for (int64_t r = 0; r + 1 < n; r += stride) {
-                const int64_t len = std::min(rp[r + 1] - rp[r], rp[r + 2] - rp[r + 1]);
-                for (int64_t j = 0; j < len; ++j) {
-                    pairs++;
-                    alike += (ci[rp[r + 1] + j] == ci[rp[r] + j] + 1);
-                }
-            }
-            if (pairs > 0 && 2 * alike > pairs) spmv_kind = LANCZOS_HIP_SPMV_ROWS;
-        }
+        if (max_span <= kTile && stats[1] > 0 && 2 * stats[2] > stats[1]) spmv_kind = LANCZOS_HIP_SPMV_ROWS;
     }
     group = pick_group(mean);
     // rows per wavefront group of the pipe kernel: the largest of 64,32,16,8,4,1
@@ -234,7 +251,10 @@ int Engine::init(const lanczos_hip_options &opt, int64_t n_, int64_t n_ext_, int
         snprintf(spmv_name, sizeof(spmv_name), "stream%s", rp64 ? "_rp64" : "");
     else
         snprintf(spmv_name, sizeof(spmv_name), "vector%d%s", group, rp64 ? "_rp64" : "");
+    return 0;
+}
 
+int Engine::alloc_state() {
     // ---- Krylov basis: every vector padded with zeros to whole tiles
     ldv = round_up(n, 2 * kTileV2);
     nvec = (reorth == LANCZOS_HIP_REORTH_NONE) ? 3 : max_iter;

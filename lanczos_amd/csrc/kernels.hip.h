@@ -807,6 +807,35 @@ k_update(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *_
     if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
 }
 
+// Matrix statistics for choosing the SpMV form: stats[0] = largest nnz span of a
+// 64-row group, stats[1] / stats[2] = over every `stride`-th row r, the number of
+// entry positions shared with row r+1 / how many of them hold col(r+1,j) == col(r,j)+1.
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_row_stats(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, int64_t stride,
+            unsigned long long *__restrict__ stats) {
+    const int64_t groups = (n + 63) >> 6;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    unsigned long long span = 0, pairs = 0, alike = 0;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += step) {
+        const int64_t r1 = (g + 1) * 64 < n ? (g + 1) * 64 : n;
+        const unsigned long long s = (unsigned long long)(rp[r1] - rp[g * 64]);
+        span = s > span ? s : span;
+    }
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t * stride + 1 < n; t += step) {
+        const int64_t r = t * stride;
+        const RP a0 = rp[r], a1 = rp[r + 1], a2 = rp[r + 2];
+        const RP len = (a1 - a0) < (a2 - a1) ? (a1 - a0) : (a2 - a1);
+        for (RP j = 0; j < len; ++j) {
+            pairs++;
+            alike += (col[a1 + j] == col[a0 + j] + 1);
+        }
+    }
+    if (span) atomicMax(&stats[0], span);
+    if (pairs) atomicAdd(&stats[1], pairs);
+    if (alike) atomicAdd(&stats[2], alike);
+}
+
 // 64-bit column indices -> 32-bit (matrix upload)
 __global__ void __launch_bounds__(kBlock)
 k_narrow_i64(const int64_t *__restrict__ in, int32_t *__restrict__ out, int64_t count) {

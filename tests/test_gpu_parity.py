@@ -128,6 +128,45 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
         la.Engine(big, 3, spmv="rows")
 
 
+def test_device_coo_to_crs_is_bit_exact(gpu, golden_dir):
+    """Device build against the reference's own crs.c output and against the host build."""
+    from test_oracle_golden import CASES, read_ref_bin
+    for name in CASES:
+        for swap in (0, 1):
+            ref = read_ref_bin(os.path.join(golden_dir, f"ref_{name}_swap{swap}.bin"))
+            coo, dim = la.read_mat_coo_incremental(os.path.join(golden_dir, f"triplets_{name}.txt"))
+            with la.Engine.from_coo(coo, dim, swap, 3) as e:
+                got = e.download_crs(coo.shape[0])
+            assert got.values.tobytes() == ref["values"].tobytes(), (name, swap)
+            assert got.column_index.tobytes() == ref["cols"].tobytes()
+            assert got.row_head_indexes.tobytes() == ref["head"].tobytes()
+    # larger: shuffled duplicates, empty rows at both ends, 1.5M entries
+    rng = np.random.default_rng(21)
+    n, m = 200000, 1500000
+    coo = np.zeros(m, la.COO_DTYPE)
+    coo["index_row"] = rng.integers(100, n - 100, m)
+    coo["index_column"] = rng.integers(0, n, m)
+    coo["value"] = rng.standard_normal(m)
+    for swap in (0, 1):
+        want = la.convert_from_coo(coo, n, swap)
+        with la.Engine.from_coo(coo, n, swap, 3) as e:
+            got = e.download_crs(m)
+            x = rng.standard_normal(n)
+            y = e.spmv(x)
+        assert got.values.tobytes() == want.values.tobytes()
+        assert got.column_index.tobytes() == want.column_index.tobytes()
+        assert got.row_head_indexes.tobytes() == want.row_head_indexes.tobytes()
+        ref_y = oracle.matvec_crs(want.row_head_indexes, want.column_index, want.values, x)
+        assert np.all(np.abs(y - ref_y) <= spmv_tolerance(want, x))
+    bad = coo[:10].copy()
+    bad["index_row"][7] = n
+    with pytest.raises(la.LanczosHipError, match=r"index out of range at entry 7 \(row=200000"):
+        la.Engine.from_coo(bad, n, 0, 3)
+    empty = np.zeros(0, la.COO_DTYPE)
+    with la.Engine.from_coo(empty, 5, 0, 3) as e:
+        assert np.all(e.spmv(np.ones(5)) == 0)
+
+
 def test_create_rejects_bad_matrices(gpu):
     a = la.synth_laplacian(1, 100)
     bad = la.CrsMatrix(a.values, a.column_index.copy(), a.row_head_indexes)
