@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="lap256", choices=sorted(WORKLOADS))
-    ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none"])
+    ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none", "selective"])
     ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",

@@ -102,7 +102,12 @@ enum {
     LANCZOS_HIP_REORTH_MGS = 3,         /* all l < k, one basis vector at a time in
                                            ascending l: the exact order of
                                            src/lanczos.c:156-167 */
-    LANCZOS_HIP_REORTH_FULL2 = 4        /* all l < k, two blocked passes */
+    LANCZOS_HIP_REORTH_FULL2 = 4,       /* all l < k, two blocked passes */
+    LANCZOS_HIP_REORTH_SELECTIVE = 5    /* all l <= k in one blocked pass, but only in the
+                                           steps where the tracked loss of orthogonality
+                                           passes sqrt(eps), and in the step after each
+                                           (the reference has a fixed rule instead:
+                                           src/lanczos_cuda.c:679-687) */
 };
 
 enum {
@@ -311,6 +316,32 @@ int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, d
 /* Copy alpha/beta history [0, iterations) from the device (row-partitioned
  * runs record the reduced values as the phases consume them). */
 int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_out, int count);
+
+/* ---- selective reorthogonalisation: the decision rule on its own --------
+ * No counterpart in the reference, whose solvers reorthogonalise by fixed
+ * rules (src/lanczos.c:156-167, src/lanczos_cuda.c:679-687).  The tracker
+ * follows estimates of v_j . v_i through the recurrence the tridiagonal
+ * entries imply.  Host arithmetic only.  lanczos_hip_run drives one itself
+ * under LANCZOS_HIP_REORTH_SELECTIVE; row-partitioned runs, whose ranks all
+ * hold the same alpha and beta, drive one per rank and reach the same
+ * decisions.  `step` is called once per iteration j = 0, 1, ... with alpha_j
+ * and the norm beta_j of the vector under construction after the three-term
+ * recurrence; it returns 1 when that vector must now be reorthogonalised
+ * against v_0..v_j (the caller then reports the new norm with `set_beta`),
+ * 0 when not, and -1 on a call out of order. */
+typedef struct lanczos_hip_omega lanczos_hip_omega;
+lanczos_hip_omega *lanczos_hip_omega_create(int max_steps);
+void lanczos_hip_omega_destroy(lanczos_hip_omega *o);
+void lanczos_hip_omega_reset(lanczos_hip_omega *o);
+int lanczos_hip_omega_step(lanczos_hip_omega *o, int j, double alpha_j, double beta_j, double *estimate);
+void lanczos_hip_omega_set_beta(lanczos_hip_omega *o, int j, double beta_j);
+int lanczos_hip_omega_reorths(const lanczos_hip_omega *o);
+size_t lanczos_hip_omega_state_doubles(const lanczos_hip_omega *o);
+void lanczos_hip_omega_state_save(const lanczos_hip_omega *o, double *out);
+int lanczos_hip_omega_state_load(lanczos_hip_omega *o, const double *in);
+/* steps of this engine's current run that reorthogonalised (every step but the
+ * first under the fixed rules) */
+int lanczos_hip_reorth_steps(const lanczos_hip_engine *e);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ class Options(C.Structure):
                 ("x_ext", C.c_void_p)]
 
 
-REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "mgs": 3, "full2": 4}
+REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "mgs": 3, "full2": 4, "selective": 5}
 SPMV = {"auto": 0, "vector": 1, "stream": 2, "pipe": 3, "pipe_nt": 4, "rows": 5}
 KERNEL_CLASSES = ("spmv", "recur", "scale", "dots", "update", "small")
 
@@ -80,6 +80,20 @@ _hip.lanczos_hip_run.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
 _hip.lanczos_hip_run.restype = C.c_int
 _hip.lanczos_hip_iterations.argtypes = [C.c_void_p]
 _hip.lanczos_hip_iterations.restype = C.c_int
+_hip.lanczos_hip_reorth_steps.argtypes = [C.c_void_p]
+_hip.lanczos_hip_reorth_steps.restype = C.c_int
+_hip.lanczos_hip_omega_create.argtypes = [C.c_int]
+_hip.lanczos_hip_omega_create.restype = C.c_void_p
+_hip.lanczos_hip_omega_destroy.argtypes = [C.c_void_p]
+_hip.lanczos_hip_omega_destroy.restype = None
+_hip.lanczos_hip_omega_reset.argtypes = [C.c_void_p]
+_hip.lanczos_hip_omega_reset.restype = None
+_hip.lanczos_hip_omega_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_double)]
+_hip.lanczos_hip_omega_step.restype = C.c_int
+_hip.lanczos_hip_omega_set_beta.argtypes = [C.c_void_p, C.c_int, C.c_double]
+_hip.lanczos_hip_omega_set_beta.restype = None
+_hip.lanczos_hip_omega_reorths.argtypes = [C.c_void_p]
+_hip.lanczos_hip_omega_reorths.restype = C.c_int
 _hip.lanczos_hip_spmv.argtypes = [C.c_void_p, _dp, _dp]
 _hip.lanczos_hip_spmv.restype = C.c_int
 _hip.lanczos_hip_get_vector.argtypes = [C.c_void_p, C.c_int, _dp]
@@ -268,6 +282,38 @@ def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float)
     return rc, eig[:max(nth_eig, 0)]
 
 
+class OmegaTracker:
+    """Decision rule of selective reorthogonalisation (host arithmetic on alpha/beta only)."""
+
+    def __init__(self, max_steps: int):
+        self._h = _hip.lanczos_hip_omega_create(max_steps)
+        if not self._h:
+            raise LanczosHipError("lanczos_hip_omega_create failed")
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _hip.lanczos_hip_omega_destroy(self._h)
+            self._h = None
+
+    def reset(self):
+        _hip.lanczos_hip_omega_reset(self._h)
+
+    def step(self, j: int, alpha: float, beta: float):
+        """-> (reorthogonalise now?, largest estimate of |v_{j+1} . v_i|)"""
+        est = C.c_double(0.0)
+        rc = _hip.lanczos_hip_omega_step(self._h, j, alpha, beta, C.byref(est))
+        if rc < 0:
+            raise LanczosHipError(f"orthogonality tracker called out of order at step {j}")
+        return bool(rc), est.value
+
+    def set_beta(self, j: int, beta: float):
+        _hip.lanczos_hip_omega_set_beta(self._h, j, beta)
+
+    @property
+    def reorths(self) -> int:
+        return _hip.lanczos_hip_omega_reorths(self._h)
+
+
 class Engine:
     """Handle API: one matrix resident on one GPU."""
 
@@ -333,6 +379,10 @@ class Engine:
     @property
     def iterations(self) -> int:
         return _hip.lanczos_hip_iterations(self._h)
+
+    @property
+    def reorth_steps(self) -> int:
+        return _hip.lanczos_hip_reorth_steps(self._h)
 
     def set_start(self, v0):
         v0 = _f64(v0)

@@ -13,9 +13,10 @@
 namespace {
 
 struct Header {
-    char magic[8];        // "LZCKPT1"
+    char magic[8];        // "LZCKPT2"
     int64_t n, ldv;
     int32_t reorth, max_iter, nvec, k, lazy, lazy_flushed_k, alpha_count, norm_count, max_blocks, hist_cap;
+    int32_t reorth_steps, tracker_doubles;
 };
 
 constexpr size_t kChunk = (size_t)8 << 20;  // doubles per staging piece (64 MiB)
@@ -50,7 +51,7 @@ extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *p
     if (!fp) return lz::fail("lanczos_hip_checkpoint_save: cannot open %s", path);
     Header h;
     memset(&h, 0, sizeof h);
-    memcpy(h.magic, "LZCKPT1", 8);
+    memcpy(h.magic, "LZCKPT2", 8);
     h.n = e->n;
     h.ldv = e->ldv;
     h.reorth = e->reorth;
@@ -63,10 +64,15 @@ extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *p
     h.norm_count = e->norm_count;
     h.max_blocks = e->max_blocks;
     h.hist_cap = e->hist_cap;
+    h.reorth_steps = e->reorth_steps;
+    std::vector<double> tracker(lanczos_hip_omega_state_doubles(e->omega));
+    if (e->omega) lanczos_hip_omega_state_save(e->omega, tracker.data());
+    h.tracker_doubles = (int32_t)tracker.size();
     // resident vectors: slots 0..k+... of a full basis, or all 3 ring slots
     const int slots = (e->reorth == LANCZOS_HIP_REORTH_NONE) ? 3 : std::min(e->k + 1, e->nvec);
     std::vector<double> stage(std::min(kChunk, (size_t)e->ldv * (size_t)std::max(slots, 1)));
     int bad = fwrite(&h, sizeof h, 1, fp) != 1;
+    bad = bad || fwrite(tracker.data(), sizeof(double), tracker.size(), fp) != tracker.size();
     bad = bad || copy_out(fp, e->d_alpha, (size_t)e->k, stage) || copy_out(fp, e->d_beta, (size_t)e->k, stage);
     bad = bad || copy_out(fp, e->d_scal, 8, stage);
     bad = bad || copy_out(fp, e->d_partials, (size_t)e->max_blocks, stage);
@@ -85,13 +91,14 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     FILE *fp = fopen(path, "rb");
     if (!fp) return lz::fail("lanczos_hip_checkpoint_load: cannot open %s", path);
     Header h;
-    if (fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "LZCKPT1", 8) != 0) {
+    if (fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "LZCKPT2", 8) != 0) {
         fclose(fp);
         return lz::fail("lanczos_hip_checkpoint_load: %s is not a checkpoint", path);
     }
     // the engine must have been created for the same matrix shape and mode
     if (h.n != e->n || h.ldv != e->ldv || h.reorth != e->reorth || h.max_blocks != e->max_blocks ||
-        h.lazy != (int)e->lazy || h.k > e->hist_cap || (e->reorth != LANCZOS_HIP_REORTH_NONE && h.k + 1 > e->nvec)) {
+        h.lazy != (int)e->lazy || h.k > e->hist_cap ||
+        (size_t)h.tracker_doubles != lanczos_hip_omega_state_doubles(e->omega) || (e->reorth != LANCZOS_HIP_REORTH_NONE && h.k + 1 > e->nvec)) {
         fclose(fp);
         return lz::fail("lanczos_hip_checkpoint_load: checkpoint (n=%lld, reorth=%d, k=%d) does not fit this engine "
                         "(n=%lld, reorth=%d, max_iter=%d)", (long long)h.n, h.reorth, h.k, (long long)e->n, e->reorth,
@@ -99,7 +106,10 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     }
     const int slots = (e->reorth == LANCZOS_HIP_REORTH_NONE) ? 3 : std::min(h.k + 1, e->nvec);
     std::vector<double> stage(std::min(kChunk, (size_t)e->ldv * (size_t)std::max(slots, 1)));
-    int bad = hipMemset(e->d_V, 0, sizeof(double) * (size_t)e->ldv * (size_t)e->nvec) != hipSuccess;
+    std::vector<double> tracker((size_t)h.tracker_doubles);
+    int bad = fread(tracker.data(), sizeof(double), tracker.size(), fp) != tracker.size();
+    if (!bad && e->omega) bad = lanczos_hip_omega_state_load(e->omega, tracker.data()) != 0;
+    bad = bad || hipMemset(e->d_V, 0, sizeof(double) * (size_t)e->ldv * (size_t)e->nvec) != hipSuccess;
     bad = bad || copy_in(fp, e->d_alpha, (size_t)h.k, stage) || copy_in(fp, e->d_beta, (size_t)h.k, stage);
     bad = bad || copy_in(fp, e->d_scal, 8, stage);
     bad = bad || copy_in(fp, e->d_partials, (size_t)e->max_blocks, stage);
@@ -111,6 +121,17 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     e->lazy_flushed_k = h.lazy_flushed_k;
     e->alpha_count = h.alpha_count;
     e->norm_count = h.norm_count;
+    e->reorth_steps = h.reorth_steps;
+    if (e->h_hist) {  // the host mirror the selective rule reads beta_{k-1} from
+        std::vector<double> a((size_t)h.k), b((size_t)h.k);
+        if (h.k > 0 && (hipMemcpy(a.data(), e->d_alpha, sizeof(double) * h.k, hipMemcpyDeviceToHost) != hipSuccess ||
+                        hipMemcpy(b.data(), e->d_beta, sizeof(double) * h.k, hipMemcpyDeviceToHost) != hipSuccess))
+            return lz::fail("lanczos_hip_checkpoint_load: history read-back failed");
+        for (int i = 0; i < h.k; ++i) {
+            e->h_hist[2 * (size_t)i] = a[(size_t)i];
+            e->h_hist[2 * (size_t)i + 1] = b[(size_t)i];
+        }
+    }
     e->started = true;
     return 0;
 }

@@ -47,6 +47,12 @@ struct Engine {
     double *d_alpha = nullptr, *d_beta = nullptr;
     int hist_cap = 0;
     double *h_hist = nullptr;  // pinned mirror {alpha_k, beta_k} for the pipelined host loop
+    // selective reorthogonalisation: the host decides per step from alpha and the
+    // norm after the recurrence, which one small kernel mirrors into pinned memory
+    lanczos_hip_omega *omega = nullptr;
+    double *h_sel = nullptr;
+    hipEvent_t sel_event = nullptr;
+    int reorth_steps = 0;
     // stream
     hipStream_t stream = nullptr;
     bool own_stream = false;
@@ -101,6 +107,7 @@ struct Engine {
     int phase_update(double *red);
     int phase_scale(double *red);
     int enqueue_iteration();
+    int selective_tail();
     int run(int steps, double *alpha_out, double *beta_out);
     int spmv_host(const double *x_host, double *y_host);
     int enable_host_history();

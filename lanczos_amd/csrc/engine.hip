@@ -97,7 +97,7 @@ static int read_options(lanczos_hip_options *opt, const lanczos_hip_options *opt
     memset(opt, 0, sizeof(*opt));
     opt->device = -1;
     if (opt_in) memcpy(opt, opt_in, std::min(sizeof(*opt), opt_in->struct_size));
-    if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_FULL2)
+    if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_SELECTIVE)
         return fail("lanczos_hip_create: bad reorth mode %d", opt->reorth);
     if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_ROWS)
         return fail("lanczos_hip_create: bad spmv_kernel %d", opt->spmv_kernel);
@@ -278,6 +278,14 @@ int Engine::alloc_state() {
     HIP_TRY(hipMalloc(&d_beta, sizeof(double) * hist_cap));
     HIP_TRY(hipMemsetAsync(d_alpha, 0, sizeof(double) * hist_cap, stream));
     HIP_TRY(hipMemsetAsync(d_beta, 0, sizeof(double) * hist_cap, stream));
+    if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) {
+        omega = lanczos_hip_omega_create(max_iter);
+        if (!omega) return fail("lanczos_hip_create: no memory for the orthogonality tracker");
+        if (int rc = enable_host_history()) return rc;
+        HIP_TRY(hipHostMalloc((void **)&h_sel, sizeof(double) * 8, hipHostMallocDefault));
+        memset(h_sel, 0, sizeof(double) * 8);
+        HIP_TRY(hipEventCreateWithFlags(&sel_event, hipEventDisableTiming));
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     k = 0;
     started = false;
@@ -301,6 +309,9 @@ Engine::~Engine() {
     (void)hipFree(d_alpha);
     (void)hipFree(d_beta);
     if (h_hist) (void)hipHostFree(h_hist);
+    if (h_sel) (void)hipHostFree(h_sel);
+    if (sel_event) (void)hipEventDestroy(sel_event);
+    lanczos_hip_omega_destroy(omega);
     if (own_stream && stream) (void)hipStreamDestroy(stream);
 }
 
@@ -473,6 +484,8 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
     k = 0;
     lazy_flushed_k = 0;
     norm_count = 0;
+    reorth_steps = 0;
+    if (omega) lanczos_hip_omega_reset(omega);
     started = true;
     return 0;
 }
@@ -493,6 +506,7 @@ void Engine::reorth_range(int *l0, int *l1) const {
     switch (reorth) {
         case LANCZOS_HIP_REORTH_NONE: *l1 = 0; break;
         case LANCZOS_HIP_REORTH_CUDA_COMPAT: *l1 = k - 2; break;
+        case LANCZOS_HIP_REORTH_SELECTIVE: *l1 = k + 1; break;
         default: *l1 = k; break;
     }
     if (*l1 < 0) *l1 = 0;
@@ -537,7 +551,7 @@ int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
     if (int rc = launch_recur(red, 1)) return rc;
     int l0, l1;
     reorth_range(&l0, &l1);
-    if (l1 - l0 <= 0) {
+    if (l1 - l0 <= 0 || reorth == LANCZOS_HIP_REORTH_SELECTIVE) {  // selective: the caller decides about dots
         *n_red = 1;
         *is_norm = 1;
         return launch_finalize(norm_parts(k), norm_count, red);
@@ -601,8 +615,10 @@ int Engine::enqueue_iteration() {
         return 0;
     }
     if (int rc = launch_recur(d_partials, alpha_count)) return rc;
+    if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) return selective_tail();
     int l0, l1;
     reorth_range(&l0, &l1);
+    if (l1 > l0) reorth_steps += 1;
     if (reorth == LANCZOS_HIP_REORTH_MGS) {
         // exact order of src/lanczos.c:156-167: one basis vector at a time
         int nparts = 0;
@@ -618,6 +634,29 @@ int Engine::enqueue_iteration() {
             if (int rc = launch_update(l0, l1, d_red, &nparts)) return rc;
         }
     }
+    return launch_scale(norm_parts(k), norm_count);
+}
+
+// The rest of an iteration under selective reorthogonalisation.  The host needs
+// alpha_k and ||w|| to advance its orthogonality estimates, so the stream is
+// waited on once per step (the wait covers one small kernel, not the scaling).
+int Engine::selective_tail() {
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * norm_count);
+        hipLaunchKernelGGL(k_norm_host, dim3(1), dim3(kBlock), 0, stream, (const double *)norm_parts(k), norm_count,
+                           d_scal + 2, h_sel);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sel_event, stream));
+    HIP_TRY(hipEventSynchronize(sel_event));
+    if (k > 0) lanczos_hip_omega_set_beta(omega, k - 1, h_hist[2 * (size_t)(k - 1) + 1]);
+    const int need = lanczos_hip_omega_step(omega, k, h_hist[2 * (size_t)k], h_sel[0], nullptr);
+    if (need < 0) return fail("lanczos_hip: orthogonality tracker out of step at iteration %d", k);
+    if (!need) return launch_scale(d_scal + 2, 1);
+    reorth_steps += 1;
+    int nparts = 0;
+    if (int rc = launch_dots(0, k + 1, d_red)) return rc;
+    if (int rc = launch_update(0, k + 1, d_red, &nparts)) return rc;
     return launch_scale(norm_parts(k), norm_count);
 }
 
@@ -715,6 +754,8 @@ int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double 
 }
 
 int lanczos_hip_iterations(const lanczos_hip_engine *e) { return e ? E(e)->k : 0; }
+
+int lanczos_hip_reorth_steps(const lanczos_hip_engine *e) { return e ? E(e)->reorth_steps : 0; }
 
 int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host) {
     if (!e) return lz::fail("lanczos_hip_spmv: NULL engine");

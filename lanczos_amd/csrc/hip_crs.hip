@@ -36,6 +36,7 @@ int env_reorth() {
     if (!strcmp(s, "mgs")) return LANCZOS_HIP_REORTH_MGS;
     if (!strcmp(s, "cuda_compat")) return LANCZOS_HIP_REORTH_CUDA_COMPAT;
     if (!strcmp(s, "none")) return LANCZOS_HIP_REORTH_NONE;
+    if (!strcmp(s, "selective")) return LANCZOS_HIP_REORTH_SELECTIVE;
     return -1;
 }
 
@@ -72,7 +73,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
     opt.reorth = env_reorth();
     opt.profile = env_int("LANCZOS_HIP_PROFILE", 1);
     if (opt.reorth < 0) {
-        printf("LANCZOS_HIP_REORTH must be one of full|full2|mgs|cuda_compat|none\n");
+        printf("LANCZOS_HIP_REORTH must be one of full|full2|mgs|cuda_compat|none|selective\n");
         return EXIT_FAILURE;
     }
     unsigned long long seed = 123456789ULL;  // the constant of src/lanczos_cuda.c:395

@@ -700,6 +700,18 @@ k_lazy_flush(const double *__restrict__ norm_parts, int norm_count, double *__re
     }
 }
 
+// out[0] = sum of partials, host[0] = its square root: the norm a host-side
+// decision waits for while the device result stays where the next kernel reads it
+__global__ void __launch_bounds__(kBlock)
+k_norm_host(const double *__restrict__ parts, int count, double *__restrict__ out, double *host) {
+    __shared__ double red[kWavesPerBlock];
+    const double s = sum_partials(parts, count, red);
+    if (threadIdx.x == 0) {
+        out[0] = s;
+        host[0] = sqrt(s);
+    }
+}
+
 // v <- scale * v  (start-vector normalisation, src/lanczos.c:95-98)
 __global__ void __launch_bounds__(kBlock)
 k_scal_mul(double2 *__restrict__ v, int64_t n2, const double *__restrict__ norm2_p, double fixed) {

@@ -213,6 +213,13 @@ class DistLanczos:
         self.red = torch.zeros(max(max_iter, 8), dtype=torch.float64, device=device)
         self.engine = make_engine(plan, self.x_ext, max_iter)
         self.k = 0
+        self.reorth_steps = 0
+        if reorth == "selective":
+            # every rank holds the same alpha and beta, so every rank's tracker decides alike
+            from . import OmegaTracker
+            self.tracker = OmegaTracker(max_iter)
+            self.ab = torch.zeros(2, dtype=torch.float64, device=device)
+            self.last_beta = 0.0
         if plan.mode == "halo":
             # what the neighbours need from this slab
             need = comm.all_gather_ints([plan.halo_lo, plan.halo_hi])
@@ -230,6 +237,9 @@ class DistLanczos:
         norm2 = float(t.cpu()[0])
         self.engine.set_start_scaled(v0_local, 1.0 / np.sqrt(norm2))
         self.k = 0
+        self.reorth_steps = 0
+        if self.reorth == "selective":
+            self.tracker.reset()
 
     # -- the vector exchange --------------------------------------------------
     def exchange(self):
@@ -255,9 +265,26 @@ class DistLanczos:
         self.exchange()
         e.phase_spmv(red)
         self.comm.all_reduce_sum(red[:1])                 # alpha
+        if self.reorth == "selective":
+            self.ab[0:1].copy_(red[:1])
         n_red, is_norm = e.phase_recur(red)
         self.comm.all_reduce_sum(red[:n_red])             # reorth coefficients, or beta^2
-        if not is_norm:
+        if self.reorth == "selective":
+            # the one host round trip per step: alpha_k and ||w||^2 for the decision rule
+            self.ab[1:2].copy_(red[:1])
+            alpha, norm2 = self.ab.cpu().tolist()
+            if self.k > 0:
+                self.tracker.set_beta(self.k - 1, self.last_beta)
+            need, _ = self.tracker.step(self.k, alpha, float(np.sqrt(norm2)))
+            if need:
+                self.reorth_steps += 1
+                n2 = e.phase_dots(red)
+                self.comm.all_reduce_sum(red[:n2])
+                e.phase_update(red)
+                self.comm.all_reduce_sum(red[:1])         # beta^2
+                norm2 = float(red[:1].cpu()[0])
+            self.last_beta = float(np.sqrt(norm2))
+        elif not is_norm:
             e.phase_update(red)
             if self.reorth == "full2":
                 n2 = e.phase_dots(red)

@@ -140,9 +140,10 @@ class LanczosResult:
         self.beta = beta
         self.ritz_hist = ritz_hist
         self.timing = dict(zip(("init", "spmv", "diagonalization", "reorthogonalization"), timing))
+        self.reorth_steps = int(timing[4]) if len(timing) > 4 else None  # selective mode only
 
 
-REORTH = {"full": 0, "cuda_compat": 1, "none": 2}
+REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "selective": 3}
 
 
 def lanczos_crs(row_head, cols, values, v0, nth, max_iter, threshold=0.0, reorth="full", verbose=False):
@@ -151,7 +152,7 @@ def lanczos_crs(row_head, cols, values, v0, nth, max_iter, threshold=0.0, reorth
     alpha = np.zeros(max_iter - 1, np.float64)
     beta = np.zeros(max_iter - 1, np.float64)
     hist = np.zeros((max_iter - 1, nth), np.float64)
-    timing = np.zeros(4, np.float64)
+    timing = np.zeros(5, np.float64)
     kind = C.c_int(0)
     steps = lib().orc_lanczos_crs(dim, _ip(row_head), _ip(cols), _dp(values),
                                   _dp(np.ascontiguousarray(v0, dtype=np.float64)), _dp(eig), nth, max_iter,
@@ -167,7 +168,7 @@ def lanczos_coo(coo, dim, v0, nth, max_iter, threshold=0.0, reorth="full", verbo
     alpha = np.zeros(max_iter - 1, np.float64)
     beta = np.zeros(max_iter - 1, np.float64)
     hist = np.zeros((max_iter - 1, nth), np.float64)
-    timing = np.zeros(4, np.float64)
+    timing = np.zeros(5, np.float64)
     kind = C.c_int(0)
     steps = lib().orc_lanczos_coo(coo.ctypes.data, coo.shape[0], dim,
                                   _dp(np.ascontiguousarray(v0, dtype=np.float64)), _dp(eig), nth, max_iter,

@@ -362,11 +362,16 @@ static void matvec_coo_thunk(const void *m, const double *x, double *y) {
  *               1 = the CUDA reference's range j < k-2
  *                   (src/lanczos_cuda.c:679-687)
  *               2 = none
+ *               3 = selective: the tracked estimates of v_j . v_i decide,
+ *                   step by step, whether w is orthogonalised against all
+ *                   l <= k (no counterpart in the reference; restated here
+ *                   so the GPU rule has a CPU model to be checked against)
  *   alpha_out   [max_iter-1] alpha_k as stored in T(k,k) (src/lanczos.c:113)
  *   beta_out    [max_iter-1] beta_k  (src/lanczos.c:176, 189-190)
  *   ritz_hist   optional [(max_iter-1) * nth] eigenvalues after each step
- *   timing      optional [4]: init, spmv, diagonalization, reorthogonalization
- *               seconds, the split of src/lanczos.c:208-211
+ *   timing      optional [5]: init, spmv, diagonalization, reorthogonalization
+ *               seconds, the split of src/lanczos.c:208-211; [4] = steps that
+ *               reorthogonalised (mode 3)
  *   verbose     non-zero prints the reference's stdout lines
  *               (src/lanczos.c:128-138, 186, 193)
  *
@@ -376,6 +381,62 @@ static void matvec_coo_thunk(const void *m, const double *x, double *y) {
  * negative for bad arguments / allocation failure (the reference exits the
  * process there, src/lanczos.c:28-56).
  */
+/* Estimates w(j,i) of v_j . v_i carried by the recurrence that
+ * v_i . A v_j = v_j . A v_i implies; rows j-1, j and j+1 are kept. */
+typedef struct {
+    int cap, force, reorths;
+    double anorm;
+    double *alpha, *beta, *rows[3];
+} orc_tracker;
+
+static int tracker_init(orc_tracker *t, int cap) {
+    memset(t, 0, sizeof *t);
+    t->cap = cap;
+    t->alpha = (double *)calloc((size_t)cap, sizeof(double));
+    t->beta = (double *)calloc((size_t)cap, sizeof(double));
+    for (int r = 0; r < 3; r++) t->rows[r] = (double *)calloc((size_t)cap + 2, sizeof(double));
+    if (!t->alpha || !t->beta || !t->rows[0] || !t->rows[1] || !t->rows[2]) return 1;
+    t->rows[1][0] = 1.0;
+    return 0;
+}
+
+static void tracker_free(orc_tracker *t) {
+    free(t->alpha);
+    free(t->beta);
+    for (int r = 0; r < 3; r++) free(t->rows[r]);
+}
+
+/* 1 when the vector under construction at step j must be reorthogonalised */
+static int tracker_step(orc_tracker *t, int j, double alpha_j, double beta_j) {
+    t->alpha[j] = alpha_j;
+    t->beta[j] = beta_j;
+    double reach = fabs(alpha_j) + beta_j + (j > 0 ? t->beta[j - 1] : 0.0);
+    if (reach > t->anorm) t->anorm = reach;
+    double *older = t->rows[0], *cur = t->rows[1], *next = t->rows[2];
+    double worst = 0.0;
+    for (int i = 0; i < j; i++) {
+        double s = t->beta[i] * cur[i + 1] + (t->alpha[i] - alpha_j) * cur[i];
+        if (i > 0) s += t->beta[i - 1] * cur[i - 1];
+        s -= t->beta[j - 1] * older[i];
+        s += copysign(0.2 * DBL_EPSILON * (t->beta[i] + beta_j), s);
+        next[i] = s / beta_j;
+        if (fabs(next[i]) > worst) worst = fabs(next[i]);
+    }
+    next[j] = 0.5 * DBL_EPSILON * t->anorm / beta_j;
+    if (next[j] > worst) worst = next[j];
+    next[j + 1] = 1.0;
+    int need = t->force || !(worst <= sqrt(DBL_EPSILON));
+    if (need) {
+        for (int i = 0; i <= j; i++) next[i] = DBL_EPSILON;
+        t->force = !t->force;
+        t->reorths++;
+    }
+    t->rows[0] = cur;
+    t->rows[1] = next;
+    t->rows[2] = older;
+    return need;
+}
+
 static int lanczos_core(const void *mat, orc_matvec_fn *matvec, uint64_t dim, const double *v0,
                         double *eigenvalues, int nth, int max_iter, double threshold,
                         int reorth_mode, double *alpha_out, double *beta_out, double *ritz_hist,
@@ -391,6 +452,16 @@ static int lanczos_core(const void *mat, orc_matvec_fn *matvec, uint64_t dim, co
     double *tmat = (double *)calloc((size_t)ld * ld, sizeof(double));
     double *last = (double *)calloc((size_t)nth, sizeof(double));
     if (!v || !tmat || !last) { free(v); free(tmat); free(last); *exit_kind = -2; return 0; }
+    orc_tracker trk;
+    double *hcoef = NULL;
+    if (reorth_mode == 3) {
+        hcoef = (double *)calloc((size_t)max_iter, sizeof(double));
+        if (tracker_init(&trk, max_iter) || !hcoef) {
+            tracker_free(&trk); free(hcoef); free(v); free(tmat); free(last);
+            *exit_kind = -2;
+            return 0;
+        }
+    }
 #define VEC(k) (v + (size_t)(k) * dim)
 #define TM(i, j) tmat[(size_t)(j) * ld + (i)]
     for (int i = 0; i < nth; i++) eigenvalues[i] = 0.0;
@@ -443,6 +514,37 @@ static int lanczos_core(const void *mat, orc_matvec_fn *matvec, uint64_t dim, co
         const double *vp = (k == 0) ? NULL : VEC(k - 1);
         int l_end = (reorth_mode == 0) ? k : (reorth_mode == 1 ? k - 2 : 0);
         double coeff = 0.0, beta_sq = 0.0;
+        if (reorth_mode == 3) {
+            /* recurrence, norm, decision; then one blocked pass h = V^T w, w -= V h */
+            double nrm2 = 0.0;
+#pragma omp parallel for reduction(+ : nrm2)
+            for (int i = 0; i < n; i++) {
+                double prev = vp ? vp[i] : 0.0;
+                w[i] = w[i] - beta * prev - alpha * vk[i];
+                nrm2 += w[i] * w[i];
+            }
+            if (k > 0) trk.beta[k - 1] = beta;
+            if (tracker_step(&trk, k, alpha, sqrt(nrm2))) {
+                for (int l = 0; l <= k; l++) {
+                    const double *vl = VEC(l);
+                    double c = 0.0;
+#pragma omp parallel for reduction(+ : c)
+                    for (int i = 0; i < n; i++) c += vl[i] * w[i];
+                    hcoef[l] = c;
+                }
+                nrm2 = 0.0;
+#pragma omp parallel for reduction(+ : nrm2)
+                for (int i = 0; i < n; i++) {
+                    double a = w[i];
+                    for (int l = 0; l <= k; l++) a -= VEC(l)[i] * hcoef[l];
+                    w[i] = a;
+                    nrm2 += a * a;
+                }
+            }
+            beta = sqrt(nrm2);
+#pragma omp parallel for
+            for (int i = 0; i < n; i++) w[i] /= beta;
+        } else
 #pragma omp parallel
         {
 #pragma omp for
@@ -481,6 +583,11 @@ static int lanczos_core(const void *mat, orc_matvec_fn *matvec, uint64_t dim, co
     if (*exit_kind == 0 && verbose) printf("Reached max iterations (%d)\n", max_iter);
 #undef VEC
 #undef TM
+    if (reorth_mode == 3) {
+        if (timing) timing[4] = (double)trk.reorths;
+        tracker_free(&trk);
+        free(hcoef);
+    }
     free(last);
     free(tmat);
     free(v);

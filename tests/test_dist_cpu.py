@@ -58,7 +58,7 @@ class NumpyPhaseEngine:
         dst.copy_(torch.from_numpy(self.V[k]))
 
     def _range(self):
-        return {"none": 0, "cuda_compat": max(self.k - 2, 0)}.get(self.reorth, self.k)
+        return {"none": 0, "cuda_compat": max(self.k - 2, 0), "selective": self.k + 1}.get(self.reorth, self.k)
 
     def phase_spmv(self, red):
         self.V[self.k + 1] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
@@ -71,7 +71,7 @@ class NumpyPhaseEngine:
         prev = self.V[self.k - 1] if self.k > 0 else 0.0
         w[:] = (w - self.beta_prev * prev) - alpha * self.V[self.k]
         nl = self._range()
-        if nl == 0:
+        if nl == 0 or self.reorth == "selective":
             red[0] = float(w @ w)
             return 1, True
         red[:nl] = torch.from_numpy(self.V[:nl] @ w)
@@ -140,30 +140,39 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     if rank == 0:
         ref = oracle.lanczos_crs(full.row_head_indexes, full.column_index, full.values, v0, 4, steps + 1, 0.0,
                                  {"full2": "full"}.get(reorth, reorth))
+        if reorth == "selective":
+            assert runner.reorth_steps == ref.reorth_steps and (steps < 100 or runner.reorth_steps >= 2)
+        ritz = la.ritz_values(alpha, beta, steps, 4)
         q.put((chosen, float(np.max(np.abs(alpha - ref.alpha) / np.abs(ref.alpha))),
-               float(np.max(np.abs(beta - ref.beta) / np.abs(ref.beta)))))
+               float(np.max(np.abs(beta - ref.beta) / np.abs(ref.beta))),
+               float(np.max(np.abs(ritz - ref.eigenvalues) / np.abs(ref.eigenvalues)))))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,kind,mode,reorth,expect_mode", [
-    (2, "lap2d", "auto", "full", "halo"),
-    (3, "lap2d", "auto", "none", "halo"),
-    (2, "lap2d", "allgather", "full2", "allgather"),
-    (2, "random", "auto", "full", "allgather"),
-    (3, "random", "auto", "cuda_compat", "allgather"),
+@pytest.mark.parametrize("world,kind,mode,reorth,expect_mode,steps", [
+    (2, "lap2d", "auto", "full", "halo", 25),
+    (3, "lap2d", "auto", "none", "halo", 25),
+    (2, "lap2d", "allgather", "full2", "allgather", 25),
+    (2, "random", "auto", "full", "allgather", 25),
+    (3, "random", "auto", "cuda_compat", "allgather", 25),
+    (2, "lap2d", "auto", "selective", "halo", 150),
 ])
-def test_partitioned_run_matches_single_process(world, kind, mode, reorth, expect_mode):
+def test_partitioned_run_matches_single_process(world, kind, mode, reorth, expect_mode, steps):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, mode, reorth, 25, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, mode, reorth, steps, q)) for r in range(world)]
     for p in procs:
         p.start()
-    chosen, ea, eb = q.get(timeout=240)
+    chosen, ea, eb, er = q.get(timeout=240)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert chosen == expect_mode
     # same arithmetic up to summation order across slabs: 1e-12 relative over 25 steps
-    assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+    assert er < 1e-10
+    if reorth != "selective":
+        assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+    # (selective: the same decisions as the single-process model are asserted in the worker; late
+    # alpha/beta of a semi-orthogonal run are sensitive to summation order, the Ritz values are not)

@@ -304,6 +304,55 @@ def test_ritz_vectors_have_small_residuals(gpu):
             e.ritz_vectors(4, 1)
 
 
+def test_selective_reorthogonalisation(gpu, tmp_path):
+    """Same decisions and sequences as the CPU model of the rule; Ritz values as with full
+    reorthogonalisation (src/lanczos.c:156-167) at equal step counts; basis semi-orthogonal."""
+    a = la.synth_laplacian(3, 24)
+    v0 = la.gaussian_fill(1, 0, a.dimension)
+    steps = 300
+    args = (a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0)
+    full = oracle.lanczos_crs(*args, "full")
+    sel = oracle.lanczos_crs(*args, "selective")
+    with la.Engine(a, steps + 1, reorth="selective") as e:
+        e.set_start(v0)
+        alpha, beta = e.run(steps)
+        assert e.reorth_steps == sel.reorth_steps
+        assert 2 <= e.reorth_steps <= steps // 10
+        V = np.stack([e.get_vector(k) for k in range(steps + 1)])
+    # early sequences agree closely; late ones of a semi-orthogonal run are sensitive to summation order
+    assert rel_err(alpha[:100], sel.alpha[:100]) < 1e-9 and rel_err(beta[:100], sel.beta[:100]) < 1e-9
+    # The cube's spectrum is degenerate: later copies of a multiple eigenvalue grow out of rounding
+    # noise at a run-dependent step, so beyond step 100 only the settled values are compared.
+    for k in (50, 100):
+        assert rel_err(la.ritz_values(alpha, beta, k, 4), full.ritz_hist[k - 1]) < 1e-10
+    assert rel_err(la.ritz_values(alpha, beta, 300, 2), full.ritz_hist[299][:2]) < 1e-10
+    gram = V @ V.T - np.eye(steps + 1)
+    assert np.max(np.abs(gram)) < 4 * np.sqrt(np.finfo(float).eps)
+    assert np.max(np.abs(gram)) > 1e-12          # and it really did skip work
+    # interrupted and resumed: bit for bit the same
+    path = str(tmp_path / "sel.bin")
+    with la.Engine(a, steps + 1, reorth="selective") as e:
+        e.set_start(v0)
+        a1, b1 = e.run(130)
+        e.checkpoint_save(path)
+    with la.Engine(a, steps + 1, reorth="selective") as e:
+        e.checkpoint_load(path)
+        a2, b2 = e.run(steps - 130)
+    assert np.concatenate([a1, a2]).tobytes() == alpha.tobytes()
+    assert np.concatenate([b1, b2]).tobytes() == beta.tobytes()
+    # an irregular matrix with clustered converging values
+    # an irregular matrix with a simple spectrum: every step comparable
+    a = la.synth_random_symmetric(4000, 10, 3)
+    v0 = la.gaussian_fill(2, 0, a.dimension)
+    full = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 201, 0.0, "full")
+    with la.Engine(a, 201, reorth="selective") as e:
+        e.set_start(v0)
+        alpha, beta = e.run(200)
+        assert 2 <= e.reorth_steps < 100
+    for k in (25, 50, 100, 150, 200):
+        assert rel_err(la.ritz_values(alpha, beta, k, 4), full.ritz_hist[k - 1]) < 1e-10
+
+
 def test_engine_limits(gpu):
     a = la.synth_laplacian(1, 500)
     with la.Engine(a, 5) as e:

@@ -176,3 +176,30 @@ def test_product_does_not_reach_into_the_oracle():
                 if re.search(r"\boracle\b", text):
                     bad.append(os.path.join(base, f))
     assert not bad, bad
+
+
+def test_orthogonality_tracker_follows_the_cpu_model():
+    """The product's decision rule against the oracle's selective run: fed the oracle's own
+    alpha/beta it asks for reorthogonalisation in the same number of steps, in pairs."""
+    import oracle
+    a = la.synth_laplacian(3, 16)
+    v0 = la.gaussian_fill(4, 0, a.dimension)
+    steps = 200
+    sel = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0, "selective")
+    none = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, steps + 1, 0.0, "none")
+    t = la.OmegaTracker(steps)
+    fired = []
+    for j in range(steps):
+        if j > 0:
+            t.set_beta(j - 1, sel.beta[j - 1])
+        # sel.beta[j] is the norm after a possible reorthogonalisation, which differs from the
+        # norm before it by O(eps): the decisions are the same
+        need, est = t.step(j, sel.alpha[j], sel.beta[j])
+        if need:
+            fired.append(j)
+    assert t.reorths == sel.reorth_steps == len(fired) and len(fired) >= 2
+    assert all(fired[i + 1] == fired[i] + 1 for i in range(0, len(fired) - 1, 2))   # pairs
+    with pytest.raises(la.LanczosHipError, match="out of order"):
+        t.step(5, 1.0, 1.0)
+    # without reorthogonalisation the estimate bounds the real loss: first firing precedes it
+    assert none.steps == steps
