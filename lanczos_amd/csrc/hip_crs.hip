@@ -165,7 +165,12 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
 
 cleanup:
     double t_spmv = 0.0, t_reorth = 0.0;
+    int iterations = 0, reorth_steps = 0;
+    char kernel_name[32] = "";
     if (e) {
+        iterations = e->k;
+        reorth_steps = e->reorth_steps;
+        snprintf(kernel_name, sizeof kernel_name, "%s", e->spmv_name);
         (void)hipStreamSynchronize(e->stream);
         e->harvest_profile();
         t_spmv = e->prof_ms[LANCZOS_HIP_K_SPMV] * 1e-3;
@@ -179,6 +184,14 @@ cleanup:
     fprintf(stderr, "[TOTAL] name=spmv sec=%.6f\n", t_spmv);
     fprintf(stderr, "[TOTAL] name=diagonalization sec=%.6f\n", time_diag);
     fprintf(stderr, "[TOTAL] name=reorthogonalization sec=%.6f\n", t_reorth);
-    fprintf(stderr, "[TOTAL] name=wall sec=%.6f\n", now_sec() - t_start);
+    const double wall = now_sec() - t_start;
+    fprintf(stderr, "[TOTAL] name=wall sec=%.6f\n", wall);
+    if (env_int("LANCZOS_HIP_JSON", 0))  // the same split, one machine-readable line
+        fprintf(stderr,
+                "{\"lanczos_hip\": {\"status\": %d, \"dimension\": %zu, \"nnz\": %zu, \"iterations\": %d, "
+                "\"reorth_steps\": %d, \"spmv_kernel\": \"%s\", \"sec\": {\"init\": %.6f, \"spmv\": %.6f, "
+                "\"diagonalization\": %.6f, \"reorthogonalization\": %.6f, \"wall\": %.6f}}}\n",
+                status, mat->dimension, mat->length, iterations, reorth_steps, kernel_name, time_init, t_spmv,
+                time_diag, t_reorth, wall);
     return status;
 }

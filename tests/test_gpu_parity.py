@@ -430,6 +430,15 @@ def test_dropin_matches_oracle_and_prints_reference_lines(gpu):
     assert step_lines[49] == "50\t" + want + "\t"
     for name in ("init", "spmv", "diagonalization", "reorthogonalization"):
         assert f"[TOTAL] name={name}" in err
+    assert "lanczos_hip" not in err                       # the JSON line is opt-in
+    # selective mode through the environment, with the machine-readable timing line
+    res, out, err = run_dropin(a, 4, 101, 0.0, env={"LANCZOS_HIP_REORTH": "selective", "LANCZOS_HIP_JSON": "1",
+                                                    "LANCZOS_HIP_QUIET": "1"})
+    assert res["rc"] == 0 and rel_err(res["eig"], o.eigenvalues) < 1e-10
+    rec = json.loads([ln for ln in err.splitlines() if ln.startswith("{")][0])["lanczos_hip"]
+    assert rec["iterations"] == 100 and rec["dimension"] == 10000 and rec["status"] == 0
+    assert rec["reorth_steps"] < 50 and set(rec["sec"]) == {"init", "spmv", "diagonalization",
+                                                            "reorthogonalization", "wall"}
 
 
 def test_dropin_convergence_exits_follow_the_cpu_rule(gpu):
