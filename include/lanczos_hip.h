@@ -343,6 +343,50 @@ int lanczos_hip_omega_state_load(lanczos_hip_omega *o, const double *in);
  * first under the fixed rules) */
 int lanczos_hip_reorth_steps(const lanczos_hip_engine *e);
 
+/* ---- block variant (block width 16, full reorthogonalisation) -------------
+ * No counterpart in the reference, whose solvers iterate on one vector
+ * (src/lanczos.c:104-191).  Sixteen vectors per step turn the
+ * reorthogonalisation against the Krylov basis (src/lanczos.c:156-167) into a
+ * tall-skinny dense contraction for the fp64 matrix cores and let the sparse
+ * product gather whole 128-byte rows.  Blocks are n x 16, row-major.  T is
+ * block tridiagonal: A_j (16 x 16, symmetric) on the diagonal, B_j (upper
+ * triangular) below it, both row-major. */
+typedef struct lanczos_hip_block lanczos_hip_block;
+enum {
+    LANCZOS_HIP_BK_SPMM = 0,
+    LANCZOS_HIP_BK_GRAM = 1,
+    LANCZOS_HIP_BK_UPDATE = 2,
+    LANCZOS_HIP_BK_SCALE = 3,
+    LANCZOS_HIP_BK_SMALL = 4,
+    LANCZOS_HIP_BK_COUNT = 5
+};
+/* matrix arguments as lanczos_hip_create; room for max_steps block steps */
+int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, const int64_t *row_head_indexes,
+                             const int64_t *column_index, const double *values, int max_steps,
+                             const lanczos_hip_options *opt);
+void lanczos_hip_block_destroy(lanczos_hip_block *b);
+/* start block: n x 16 row-major host array (orthonormalised on the device), or N(0,1) entries
+ * from lanczos_hip_gaussian_fill(seed, 0, 16 n, .) */
+int lanczos_hip_block_set_start(lanczos_hip_block *b, const double *x0_host);
+int lanczos_hip_block_set_start_seed(lanczos_hip_block *b, uint64_t seed);
+int lanczos_hip_block_run(lanczos_hip_block *b, int steps);
+int lanczos_hip_block_steps(const lanczos_hip_block *b);
+/* a_out, b_out: [steps][16][16] */
+int lanczos_hip_block_tmatrix(lanczos_hip_block *b, int steps, double *a_out, double *b_out);
+/* lowest nth eigenvalues of the leading 16 steps x 16 steps part of T */
+int lanczos_hip_block_ritz(lanczos_hip_block *b, int steps, int nth, double *eig_out);
+/* test hooks on the resident basis (slot t = block Q_t; slots above the current step are free) */
+int lanczos_hip_block_get_block(lanczos_hip_block *b, int t, double *out_host);
+int lanczos_hip_block_set_block(lanczos_hip_block *b, int t, const double *in_host);
+int lanczos_hip_block_spmm(lanczos_hip_block *b, int t_in, int t_out);            /* Q_out = A Q_in */
+int lanczos_hip_block_project(lanczos_hip_block *b, int t0, int t1, int t_w,      /* H = Q^T W; W -= Q H */
+                              double *h_out_host);
+int lanczos_hip_block_orthonormalise(lanczos_hip_block *b, int t, double *factor_out_host);
+int lanczos_hip_block_profile(const lanczos_hip_block *b, int cls, double *ms, int64_t *launches, double *bytes);
+void lanczos_hip_block_profile_reset(lanczos_hip_block *b);
+/* lowest nth eigenvalues of a dense symmetric n x n matrix (row-major, destroyed) */
+int lanczos_hip_sym_lowest_eigs(double *a, int n, int nth, double *eig);
+
 #ifdef __cplusplus
 }
 #endif

@@ -282,6 +282,135 @@ def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float)
     return rc, eig[:max(nth_eig, 0)]
 
 
+BLOCK_WIDTH = 16
+BLOCK_KERNEL_CLASSES = ("spmm", "gram", "update", "scale", "small")
+_hip.lanczos_hip_block_create.argtypes = [C.POINTER(C.c_void_p), C.c_int64, C.c_int64, _ip, _ip, _dp, C.c_int,
+                                          C.POINTER(Options)]
+_hip.lanczos_hip_block_create.restype = C.c_int
+_hip.lanczos_hip_block_destroy.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_destroy.restype = None
+_hip.lanczos_hip_block_set_start.argtypes = [C.c_void_p, _dp]
+_hip.lanczos_hip_block_set_start_seed.argtypes = [C.c_void_p, C.c_uint64]
+_hip.lanczos_hip_block_run.argtypes = [C.c_void_p, C.c_int]
+_hip.lanczos_hip_block_steps.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_tmatrix.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+_hip.lanczos_hip_block_ritz.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+_hip.lanczos_hip_block_get_block.argtypes = [C.c_void_p, C.c_int, _dp]
+_hip.lanczos_hip_block_set_block.argtypes = [C.c_void_p, C.c_int, _dp]
+_hip.lanczos_hip_block_spmm.argtypes = [C.c_void_p, C.c_int, C.c_int]
+_hip.lanczos_hip_block_project.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _dp]
+_hip.lanczos_hip_block_orthonormalise.argtypes = [C.c_void_p, C.c_int, _dp]
+_hip.lanczos_hip_block_profile.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp]
+_hip.lanczos_hip_block_profile_reset.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_profile_reset.restype = None
+_hip.lanczos_hip_sym_lowest_eigs.argtypes = [_dp, C.c_int, C.c_int, _dp]
+
+
+def sym_lowest_eigs(a: np.ndarray, nth: int) -> np.ndarray:
+    """Lowest nth eigenvalues of a dense symmetric matrix (Householder + bisection, host)."""
+    a = np.array(a, dtype=np.float64, order="C")
+    out = np.zeros(nth)
+    if _hip.lanczos_hip_sym_lowest_eigs(a.ctypes.data_as(_dp), a.shape[0], nth, out.ctypes.data_as(_dp)) != 0:
+        raise LanczosHipError("lanczos_hip_sym_lowest_eigs failed")
+    return out
+
+
+class BlockEngine:
+    """Block-Lanczos variant: 16 vectors per step, blocks are (n, 16) row-major arrays."""
+
+    def __init__(self, a: "CrsMatrix", max_steps: int, profile: bool = False, device: int = -1):
+        self._h = C.c_void_p(None)
+        self.n, self.max_steps = a.dimension, max_steps
+        opt = Options(C.sizeof(Options), device, None, 0, 0, int(profile), 0, 0, 0, None)
+        _check(_hip.lanczos_hip_block_create(C.byref(self._h), a.dimension, a.length,
+                                             a.row_head_indexes.ctypes.data_as(_ip),
+                                             a.column_index.ctypes.data_as(_ip), a.values.ctypes.data_as(_dp),
+                                             max_steps, C.byref(opt)), "lanczos_hip_block_create")
+
+    def close(self):
+        if self._h:
+            _hip.lanczos_hip_block_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_start(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert x0.shape == (self.n, BLOCK_WIDTH)
+        _check(_hip.lanczos_hip_block_set_start(self._h, x0.ctypes.data_as(_dp)), "lanczos_hip_block_set_start")
+
+    def set_start_seed(self, seed: int):
+        _check(_hip.lanczos_hip_block_set_start_seed(self._h, seed), "lanczos_hip_block_set_start_seed")
+
+    def run(self, steps: int):
+        _check(_hip.lanczos_hip_block_run(self._h, steps), "lanczos_hip_block_run")
+
+    @property
+    def steps(self) -> int:
+        return _hip.lanczos_hip_block_steps(self._h)
+
+    def tmatrix(self, steps: int = None):
+        steps = self.steps if steps is None else steps
+        a = np.zeros((steps, BLOCK_WIDTH, BLOCK_WIDTH))
+        b = np.zeros((steps, BLOCK_WIDTH, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_tmatrix(self._h, steps, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp)),
+               "lanczos_hip_block_tmatrix")
+        return a, b
+
+    def ritz(self, nth: int, steps: int = None) -> np.ndarray:
+        steps = self.steps if steps is None else steps
+        out = np.zeros(nth)
+        _check(_hip.lanczos_hip_block_ritz(self._h, steps, nth, out.ctypes.data_as(_dp)), "lanczos_hip_block_ritz")
+        return out
+
+    def get_block(self, t: int) -> np.ndarray:
+        out = np.zeros((self.n, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_get_block(self._h, t, out.ctypes.data_as(_dp)), "lanczos_hip_block_get_block")
+        return out
+
+    def set_block(self, t: int, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.n, BLOCK_WIDTH)
+        _check(_hip.lanczos_hip_block_set_block(self._h, t, x.ctypes.data_as(_dp)), "lanczos_hip_block_set_block")
+
+    def spmm(self, t_in: int, t_out: int):
+        _check(_hip.lanczos_hip_block_spmm(self._h, t_in, t_out), "lanczos_hip_block_spmm")
+
+    def project(self, t0: int, t1: int, t_w: int) -> np.ndarray:
+        h = np.zeros((t1 - t0, BLOCK_WIDTH, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_project(self._h, t0, t1, t_w, h.ctypes.data_as(_dp)),
+               "lanczos_hip_block_project")
+        return h
+
+    def orthonormalise(self, t: int) -> np.ndarray:
+        r = np.zeros((BLOCK_WIDTH, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_orthonormalise(self._h, t, r.ctypes.data_as(_dp)),
+               "lanczos_hip_block_orthonormalise")
+        return r
+
+    def profile(self) -> dict:
+        out = {}
+        for i, name in enumerate(BLOCK_KERNEL_CLASSES):
+            ms, ln, by = C.c_double(), C.c_int64(), C.c_double()
+            _check(_hip.lanczos_hip_block_profile(self._h, i, C.byref(ms), C.byref(ln), C.byref(by)),
+                   "lanczos_hip_block_profile")
+            out[name] = {"ms": ms.value, "launches": ln.value, "bytes": by.value}
+        return out
+
+    def profile_reset(self):
+        _hip.lanczos_hip_block_profile_reset(self._h)
+
+
 class OmegaTracker:
     """Decision rule of selective reorthogonalisation (host arithmetic on alpha/beta only)."""
 

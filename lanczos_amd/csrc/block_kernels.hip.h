@@ -1,0 +1,298 @@
+// Device kernels of the block-Lanczos variant (block width 16) for gfx950.
+//
+// A block of Lanczos vectors is stored row-major, n_pad x 16 doubles: one row
+// is one 128-byte line, so the SpMM gathers whole lines and the tall-skinny
+// contractions against the basis
+//     H = Q^T W   (16m x 16)         W -= Q H
+// feed v_mfma_f64_16x16x4_f64 with coalesced loads.  Both are bandwidth-bound
+// (about 4 flop per byte of basis streamed); the matrix cores are used because
+// the contraction is a dense one, not to reach their peak.
+//
+// MFMA operand maps (f64 16x16x4): lane l supplies A[i = l & 15][k = l >> 4] and
+// B[k = l >> 4][j = l & 15]; result register r of lane l is
+// D[row = (l >> 4) + 4 r][col = l & 15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lzb {
+
+constexpr int kW = 16;          // block width
+constexpr int kThreads = 256;   // 4 wavefronts
+constexpr int kTileRows = 32;   // rows of a wavefront's tile in the contraction kernels
+constexpr int kGramSeg = 8;     // basis blocks whose accumulators a wavefront holds at once
+
+typedef double d4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ d4v mfma16(double a, double b, d4v c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ double ld_nt(const double *p) { return __builtin_nontemporal_load(p); }
+
+// ---------------------------------------------------------------------------
+// SpMM  Y = A X  on row-major n_pad x 16 blocks (the block form of
+// src/crs.c:155-178).  Sixteen lanes own one row, lane c its column c; the
+// group loads 16 (col, val) pairs at a time with one coalesced load each and
+// hands them round with ds_bpermute, so every gather reads one full 128-byte
+// row of X.  Row sums run left to right in entry order.  Rows n..n_pad-1 are
+// written as zeros.  Workgroup b serves the b % 8-th eighth of the rows
+// (workgroups b and b + 8 share an XCD and its L2).
+// ---------------------------------------------------------------------------
+template <typename RP>
+__global__ void __launch_bounds__(kThreads)
+k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+         const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t quads = n_pad / 4;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
+    const int64_t q_lo = quads * xcd / 8, q_hi = quads * (xcd + 1) / 8;
+    for (int64_t q = q_lo + (int64_t)slot * 4 + wave; q < q_hi; q += (int64_t)per * 4) {
+        const int64_t r = q * 4 + g;
+        int64_t e0 = 0;
+        int len = 0;
+        if (r < n) {
+            e0 = (int64_t)rp[r];
+            len = (int)((int64_t)rp[r + 1] - e0);
+        }
+        int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
+                         max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
+        double acc = 0.0;
+        for (int p = 0; p < maxlen; p += 16) {
+            int mycol = 0;
+            double myval = 0.0;
+            if (p + c < len) {
+                mycol = col[e0 + p + c];
+                myval = val[e0 + p + c];
+            }
+            const int cnt = min(16, maxlen - p);  // wave-uniform; entries past a row's end are (col 0, val 0)
+#pragma unroll 4
+            for (int j = 0; j < cnt; ++j) {
+                const int cj = __shfl(mycol, j, 16);
+                const double vj = __shfl(myval, j, 16);
+                acc += vj * X[(int64_t)cj * kW + c];
+            }
+        }
+        Y[r * kW + c] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// hpart[wg][(t - t0) * 256 + e] = this workgroup's part of Q_t^T W in fragment
+// order (e = 64 r + lane), for basis blocks t0 <= t < t1.  A wavefront owns
+// 32-row tiles, keeps the W tile as eight B operands and one accumulator per
+// basis block of the current segment; the basis streams past once.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+k_gram16(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, const double *__restrict__ W,
+         int64_t n_pad, double *__restrict__ hpart, int64_t hstride) {
+    __shared__ double red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    const int64_t tiles = n_pad / kTileRows;
+    for (int s0 = t0; s0 < t1; s0 += kGramSeg) {
+        const int ns = min(kGramSeg, t1 - s0);
+        d4v acc[kGramSeg];
+#pragma unroll
+        for (int t = 0; t < kGramSeg; ++t) acc[t] = d4v{0.0, 0.0, 0.0, 0.0};
+        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+            const int64_t off = (tile * kTileRows + kk) * kW + cc;
+            double bw[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bw[u] = W[off + u * 64];
+#pragma unroll
+            for (int t = 0; t < kGramSeg; ++t) {
+                if (t < ns) {
+                    const double *q = Q + (int64_t)(s0 + t) * blk_stride + off;
+                    double a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = ld_nt(q + u * 64);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[t] = mfma16(a[u], bw[u], acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kGramSeg; ++t) {
+            if (t < ns) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[t][r];
+                __syncthreads();
+                const int e = threadIdx.x;
+                hpart[(int64_t)blockIdx.x * hstride + (int64_t)(s0 + t - t0) * 256 + e] =
+                    (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            }
+        }
+    }
+}
+
+// H[t][i][j] (row-major 16 x 16 per block) = sum over workgroups, in workgroup order
+__global__ void __launch_bounds__(kThreads)
+k_gram_reduce(const double *__restrict__ hpart, int groups, int64_t hstride, int count, double *__restrict__ H) {
+    const int idx = blockIdx.x * kThreads + threadIdx.x;
+    if (idx >= count) return;
+    double s = 0.0;
+#pragma unroll 8
+    for (int g = 0; g < groups; ++g) s += hpart[(int64_t)g * hstride + idx];
+    const int t = idx >> 8, e = idx & 255, r = e >> 6, lane = e & 63;
+    const int i = (lane >> 4) + 4 * r, j = lane & 15;
+    H[t * 256 + i * kW + j] = s;
+}
+
+// ---------------------------------------------------------------------------
+// W -= sum_t Q_t H_t for t0 <= t < t1.  The contraction runs over the columns
+// of Q_t, which are the fast index in memory, so a tile of Q_t is loaded
+// coalesced (lane = 4 rows x 16 columns per load), parked in the wavefront's
+// own LDS tile and read back as the A operand (16 rows x 4 columns per MFMA).
+// The LDS tile is private to a wavefront, whose LDS operations execute in
+// order: no workgroup barrier is needed.
+// ---------------------------------------------------------------------------
+constexpr int kLdsRow = 17;  // doubles per LDS tile row (16 + 1 against bank conflicts)
+
+__global__ void __launch_bounds__(kThreads)
+k_bupdate16(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, double *__restrict__ W,
+            int64_t n_pad, const double *__restrict__ H) {
+    __shared__ double lds[4][kTileRows * kLdsRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double *lt = lds[wave];
+    const int64_t tiles = n_pad / kTileRows;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t off = (tile * kTileRows + kk) * kW + cc;
+        d4v acc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[sub][r] = W[off + (sub * 16 + 4 * r) * kW];
+        double x[8];
+        {
+            const double *q = Q + (int64_t)t0 * blk_stride + off;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = ld_nt(q + u * 64);
+        }
+        for (int t = t0; t < t1; ++t) {
+            double hb[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) hb[s] = -H[(t - t0) * 256 + (4 * s + kk) * kW + cc];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int u = 0; u < 8; ++u) lt[(4 * u + kk) * kLdsRow + cc] = x[u];
+            __builtin_amdgcn_wave_barrier();
+            if (t + 1 < t1) {  // next block's tile is in flight while this one is multiplied
+                const double *q = Q + (int64_t)(t + 1) * blk_stride + off;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = ld_nt(q + u * 64);
+            }
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const double a = lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk];
+                    acc[sub] = mfma16(a, hb[s], acc[sub]);
+                }
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[off + (sub * 16 + 4 * r) * kW] = acc[sub][r];
+    }
+}
+
+// W <- W M for a 16 x 16 matrix M (row-major): the triangular solve of CholQR
+// applied as a product with the inverse factor.  Same operand handling as
+// k_bupdate16 with the tile itself as the left operand.
+__global__ void __launch_bounds__(kThreads)
+k_bscale16(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M) {
+    __shared__ double lds[4][kTileRows * kLdsRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double *lt = lds[wave];
+    double mb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mb[s] = M[(4 * s + kk) * kW + cc];
+    const int64_t tiles = n_pad / kTileRows;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t off = (tile * kTileRows + kk) * kW + cc;
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = W[off + u * 64];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lt[(4 * u + kk) * kLdsRow + cc] = x[u];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            d4v acc = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], mb[s], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[off + (sub * 16 + 4 * r) * kW] = acc[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// 16 x 16 Cholesky G = R^T R (R upper triangular), its inverse, and optionally
+// the product R * Rprev (the off-diagonal block of T after a second CholQR
+// pass).  One workgroup; thread (i, j) = (tid / 16, tid % 16).  A pivot that
+// below 1e-14 of its diagonal entry (a condition number near 1e7, the edge of
+// what CholQR twice can repair) marks the block rank deficient: status[0]
+// receives `tag` (first occurrence wins) and the pivot is replaced by 1 so
+// nothing turns NaN.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(kThreads)
+k_chol16(const double *__restrict__ G, double *__restrict__ Rinv, double *__restrict__ R,
+         const double *__restrict__ Rprev, double *__restrict__ Bout, int *__restrict__ status, int tag) {
+    __shared__ double A[16][17], X[16][17];
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    A[i][j] = 0.5 * (G[i * 16 + j] + G[j * 16 + i]);
+    __syncthreads();
+    __shared__ double diag0[16];
+    if (threadIdx.x < 16) diag0[threadIdx.x] = A[threadIdx.x][threadIdx.x];
+    __syncthreads();
+    for (int k = 0; k < 16; ++k) {
+        if (threadIdx.x == 0) {
+            double d = A[k][k];
+            if (!(d > 1e-14 * diag0[k])) {
+                if (status[0] == 0) status[0] = tag;
+                d = 1.0;
+            }
+            A[k][k] = sqrt(d);
+        }
+        __syncthreads();
+        if (i == k && j > k) A[k][j] /= A[k][k];
+        __syncthreads();
+        if (i > k && j >= i) A[i][j] -= A[k][i] * A[k][j];
+        __syncthreads();
+    }
+    if (j < i) A[i][j] = 0.0;
+    X[i][j] = 0.0;
+    __syncthreads();
+    if (threadIdx.x < 16) {  // column c of the inverse by back substitution
+        const int c = threadIdx.x;
+        X[c][c] = 1.0 / A[c][c];
+        for (int r = c - 1; r >= 0; --r) {
+            double s = 0.0;
+            for (int m = r + 1; m <= c; ++m) s += A[r][m] * X[m][c];
+            X[r][c] = -s / A[r][r];
+        }
+    }
+    __syncthreads();
+    Rinv[i * 16 + j] = X[i][j];
+    R[i * 16 + j] = A[i][j];
+    if (Bout) {
+        double s = 0.0;
+        for (int m = 0; m < 16; ++m) s += A[i][m] * Rprev[m * 16 + j];
+        Bout[i * 16 + j] = s;
+    }
+}
+
+// out = 0.5 (H + H^T) of one 16 x 16 block (the diagonal block of T)
+__global__ void __launch_bounds__(kThreads)
+k_symm16(const double *__restrict__ H, double *__restrict__ out) {
+    const int i = threadIdx.x >> 4, j = threadIdx.x & 15;
+    out[i * 16 + j] = 0.5 * (H[i * 16 + j] + H[j * 16 + i]);
+}
+
+}  // namespace lzb

@@ -1,0 +1,141 @@
+"""GPU tests of the block variant (16 vectors per step, fp64 MFMA contractions).
+
+The reference has no block form (src/lanczos.c iterates on one vector): the block-specific
+quantities are checked against the numpy model in oracle/block_lanczos.py (parity unpinned by the
+reference), the spectrum against the single-vector path that follows src/lanczos.c:104-191 and
+against closed forms.
+"""
+import numpy as np
+import pytest
+
+import lanczos_amd as la
+import oracle
+from oracle import block_lanczos as bl
+from matrices import laplacian_eigs, rel_err
+
+pytestmark = pytest.mark.gpu
+W = la.BLOCK_WIDTH
+
+
+def start_block(n, seed):
+    return la.gaussian_fill(seed, 0, n * W).reshape(n, W)
+
+
+@pytest.mark.parametrize("make", [lambda: la.synth_laplacian(3, 20), lambda: la.synth_laplacian(1, 777),
+                                  lambda: la.synth_random_symmetric(5000, 10, 3)])
+def test_spmm_matches_oracle(gpu, make):
+    a = make()
+    x = start_block(a.dimension, 11)
+    with la.BlockEngine(a, 2) as e:
+        e.set_block(0, x)
+        e.spmm(0, 1)
+        y = e.get_block(1)
+    want = bl.spmm(a.row_head_indexes, a.column_index, a.values, x)
+    bound = bl.spmm(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x))
+    assert np.all(np.abs(y - want) <= 1e-14 * bound + 1e-300)
+    # column c of the block product is the single-vector product of column c (src/crs.c:155-178)
+    col = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, np.ascontiguousarray(x[:, 5]))
+    assert np.all(np.abs(y[:, 5] - col) <= 1e-14 * bound[:, 5] + 1e-300)
+
+
+@pytest.mark.parametrize("n,nblocks", [(16, 1), (4000, 3), (33333, 11), (70001, 20)])
+def test_projection_kernels_match_numpy(gpu, n, nblocks):
+    """H = Q^T W and W -= Q H on arbitrary (non-orthogonal) data: checks the MFMA operand maps."""
+    a = la.synth_laplacian(1, n)
+    rng = np.random.default_rng(n)
+    q = [rng.standard_normal((n, W)) for _ in range(nblocks)]
+    w = rng.standard_normal((n, W))
+    with la.BlockEngine(a, nblocks + 1) as e:
+        for t, qt in enumerate(q):
+            e.set_block(t, qt)
+        e.set_block(nblocks, w)
+        h = e.project(0, nblocks, nblocks)
+        w_new = e.get_block(nblocks)
+        # a sub-range that does not start at block 0
+        if nblocks >= 3:
+            e.set_block(nblocks, w)
+            h_sub = e.project(1, nblocks - 1, nblocks)
+            w_sub = e.get_block(nblocks)
+    scale = np.sqrt(n) * 4
+    for t in range(nblocks):
+        assert np.max(np.abs(h[t] - q[t].T @ w)) < 1e-13 * scale * np.sqrt(n)
+    want = w - sum(q[t] @ (q[t].T @ w) for t in range(nblocks))
+    assert np.max(np.abs(w_new - want)) < 1e-12 * np.max(np.abs(want))
+    if nblocks >= 3:
+        for t in range(1, nblocks - 1):
+            assert np.max(np.abs(h_sub[t - 1] - q[t].T @ w)) < 1e-13 * scale * np.sqrt(n)
+        want = w - sum(q[t] @ (q[t].T @ w) for t in range(1, nblocks - 1))
+        assert np.max(np.abs(w_sub - want)) < 1e-12 * np.max(np.abs(want))
+
+
+def test_orthonormalise_is_a_qr_factorisation(gpu):
+    n = 12345
+    a = la.synth_laplacian(1, n)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((n, W)) @ rng.standard_normal((W, W))     # mildly ill conditioned
+    with la.BlockEngine(a, 1) as e:
+        e.set_block(0, x)
+        r = e.orthonormalise(0)
+        q = e.get_block(0)
+        assert np.max(np.abs(q.T @ q - np.eye(W))) < 1e-13
+        assert np.allclose(np.tril(r, -1), 0) and np.all(np.diag(r) > 0)
+        assert np.max(np.abs(q @ r - x)) < 1e-12 * np.max(np.abs(x))
+        dep = x.copy()
+        dep[:, 7] = dep[:, 3]
+        with pytest.raises(la.LanczosHipError, match="rank deficient"):
+            e.set_start(dep)
+
+
+def test_block_run_matches_the_numpy_model(gpu):
+    a = la.synth_random_symmetric(6000, 8, 5)
+    x0 = start_block(a.dimension, 21)
+    steps = 12
+    ma, mb, basis = bl.block_lanczos(a.row_head_indexes, a.column_index, a.values, x0, steps)
+    with la.BlockEngine(a, steps) as e:
+        e.set_start(x0)
+        e.run(steps)
+        assert e.steps == steps
+        ga, gb = e.tmatrix()
+        v = np.hstack([e.get_block(t) for t in range(steps + 1)])
+        for k in (1, 2, 6, 12):
+            assert rel_err(e.ritz(4, k), bl.ritz(ma, mb, k, 4)) < 1e-10
+        with pytest.raises(la.LanczosHipError, match="basis full"):
+            e.run(1)
+    assert np.max(np.abs(v.T @ v - np.eye(v.shape[1]))) < 1e-12
+    scale = np.max(np.abs(ma))
+    assert np.max(np.abs(ga[:4] - ma[:4])) < 1e-10 * scale and np.max(np.abs(gb[:4] - mb[:4])) < 1e-10 * scale
+    # T is the projection of A on the basis: V^T A V is block tridiagonal with these blocks
+    av = bl.spmm(a.row_head_indexes, a.column_index, a.values, v[:, :steps * W])
+    proj = v[:, :steps * W].T @ av
+    assert np.max(np.abs(proj - bl.assemble_t(ga, gb, steps))) < 1e-11 * scale
+
+
+def test_block_run_finds_the_spectrum_with_multiplicities(gpu):
+    """Converged values: closed form (the cube's second eigenvalue is triple: a single-vector run
+    sees one copy until rounding breeds the others, a block sees all at once) and the
+    single-vector path that follows src/lanczos.c."""
+    a = la.synth_laplacian(3, 12)
+    exact = laplacian_eigs(3, 12, 7)
+    with la.BlockEngine(a, 45) as e:
+        e.set_start_seed(9)
+        e.run(45)
+        got = e.ritz(7)
+    assert rel_err(got, exact) < 1e-10
+    assert abs(exact[1] - exact[3]) < 1e-14                          # the triple one
+    with la.Engine(a, 400) as e1:
+        e1.set_start_seed(9)
+        alpha, beta = e1.run(399)
+    single = la.ritz_values(alpha, beta, 399, 1)
+    assert rel_err(got[:1], single) < 1e-10
+
+
+def test_block_limits(gpu):
+    small = la.synth_laplacian(1, 10)
+    with pytest.raises(la.LanczosHipError, match="below the block width"):
+        la.BlockEngine(small, 2)
+    a = la.synth_laplacian(1, 100)
+    with pytest.raises(la.LanczosHipError, match="max_steps must be >= 1"):
+        la.BlockEngine(a, 0)
+    with la.BlockEngine(a, 2) as e:
+        with pytest.raises(la.LanczosHipError, match="no start block"):
+            e.run(1)
