@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none", "selective"])
     ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-block", action="store_true", help="skip the block-variant section")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")
@@ -90,6 +91,47 @@ def cpu_baseline(a, v0, steps: int) -> dict:
         "ritz": [float(x) for x in r.eigenvalues],
         "alpha": [float(x) for x in r.alpha[:steps]],
         "beta": [float(x) for x in r.beta[:steps]],
+    }
+
+
+def measured_traffic(kernel_class: str, workload: str, steps: int, reorth: str):
+    """HBM bytes per launch of one kernel class from the PMC passes (FETCH_SIZE, WRITE_SIZE, collected by
+    rocprofv3 in runs of their own over this same command and condensed into profiles/traffic.json by
+    scripts/summarize_profile.py); None when no such measurement exists for this configuration."""
+    try:
+        rec = json.load(open(os.path.join(HERE, "profiles", "traffic.json")))
+    except (OSError, ValueError):
+        return None
+    if (rec.get("workload"), rec.get("steps"), rec.get("reorth")) != (workload, steps, reorth):
+        return None
+    return rec.get("bytes_per_launch", {}).get(kernel_class)
+
+
+def block_variant(la, a, steps: int = 8) -> dict:
+    """The block variant (16 vectors per step, fp64 MFMA contractions) on the same matrix: a few block
+    steps, per-kernel achieved GB/s from HIP events, and the matrix-core rate of the Gram kernel."""
+    n = a.dimension
+    with la.BlockEngine(a, steps, profile=True) as e:
+        e.set_start_seed(123456789)
+        e.profile_reset()
+        t0 = time.perf_counter()
+        e.run(steps)
+        dt = time.perf_counter() - t0
+        prof = e.profile()
+    kernels = {}
+    for k, v in prof.items():
+        if v["launches"] and v["ms"] > 0:
+            kernels[k] = {"ms_total": v["ms"], "launches": v["launches"],
+                          "GBps": v["bytes"] / (v["ms"] * 1e-3) / 1e9}
+    # Gram: 2 * n * 16 * 16 flops per basis block streamed; bytes counted are 128 n per block
+    gram_blocks = prof["gram"]["bytes"] / (8.0 * 16 * n)
+    return {
+        "block_width": 16,
+        "block_steps": steps,
+        "ms_per_block_step": dt / steps * 1e3,
+        "vector_steps_per_s": 16 * steps / dt,
+        "kernels": kernels,
+        "gram_mfma_TFLOPs": 2.0 * n * 256 * gram_blocks / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] else 0,
     }
 
 
@@ -203,6 +245,9 @@ def single_gpu(args) -> dict:
         "ritz_lowest4": [float(x) for x in ritz],
         "setup_s": {"generate": t_gen, "upload": t_upload},
     }
+    out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, K, args.reorth)
+    if not args.no_block:
+        out["block_variant"] = block_variant(la, a)
     if not args.no_cpu_baseline:
         cb = cpu_baseline(a, v0, args.cpu_steps)
         s = min(cb["steps"], K)

@@ -32,48 +32,78 @@ __device__ __forceinline__ double ld_nt(const double *p) { return __builtin_nont
 
 // ---------------------------------------------------------------------------
 // SpMM  Y = A X  on row-major n_pad x 16 blocks (the block form of
-// src/crs.c:155-178).  Sixteen lanes own one row, lane c its column c; the
-// group loads 16 (col, val) pairs at a time with one coalesced load each and
+// src/crs.c:155-178).  Eight lanes own one row, lane c its columns 2c, 2c+1;
+// the group loads 8 (col, val) pairs at a time with one coalesced load each and
 // hands them round with ds_bpermute, so every gather reads one full 128-byte
 // row of X.  Row sums run left to right in entry order.  Rows n..n_pad-1 are
 // written as zeros.  Workgroup b serves the b % 8-th eighth of the rows
 // (workgroups b and b + 8 share an XCD and its L2).
 // ---------------------------------------------------------------------------
+typedef double d2v __attribute__((ext_vector_type(2)));
+
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
 k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__restrict__ col,
          const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y) {
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
-    const int64_t quads = n_pad / 4;
+    // eight lanes own one row, lane c its columns 2c and 2c + 1; a wavefront works on 8 rows at once
+    const int lane = threadIdx.x & 63, c = lane & 7, g = lane >> 3, wave = threadIdx.x >> 6;
+    const int64_t octs = n_pad / 8;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const int64_t q_lo = quads * xcd / 8, q_hi = quads * (xcd + 1) / 8;
-    for (int64_t q = q_lo + (int64_t)slot * 4 + wave; q < q_hi; q += (int64_t)per * 4) {
-        const int64_t r = q * 4 + g;
-        int64_t e0 = 0;
-        int len = 0;
-        if (r < n) {
+    const int64_t q_lo = octs * xcd / 8, q_hi = octs * (xcd + 1) / 8;
+    const int64_t step = (int64_t)per * 4;
+    int64_t q = q_lo + (int64_t)slot * 4 + wave;
+    // the offsets, and the first eight entries of each row, are fetched one round ahead
+    int64_t e0 = 0;
+    int len = 0, mycol = 0;
+    double myval = 0.0;
+    auto fetch = [&](int64_t qq) {
+        e0 = 0;
+        len = 0;
+        mycol = 0;
+        myval = 0.0;
+        const int64_t r = qq * 8 + g;
+        if (qq < q_hi && r < n) {
             e0 = (int64_t)rp[r];
             len = (int)((int64_t)rp[r + 1] - e0);
-        }
-        int maxlen = max(max(__builtin_amdgcn_readlane(len, 0), __builtin_amdgcn_readlane(len, 16)),
-                         max(__builtin_amdgcn_readlane(len, 32), __builtin_amdgcn_readlane(len, 48)));
-        double acc = 0.0;
-        for (int p = 0; p < maxlen; p += 16) {
-            int mycol = 0;
-            double myval = 0.0;
-            if (p + c < len) {
-                mycol = col[e0 + p + c];
-                myval = val[e0 + p + c];
+            if (c < len) {
+                mycol = __builtin_nontemporal_load(col + e0 + c);
+                myval = __builtin_nontemporal_load(val + e0 + c);
             }
-            const int cnt = min(16, maxlen - p);  // wave-uniform; entries past a row's end are (col 0, val 0)
-#pragma unroll 4
+        }
+    };
+    fetch(q);
+    for (; q < q_hi; q += step) {
+        const int64_t r = q * 8 + g;
+        const int64_t ce0 = e0;
+        const int clen = len;
+        int ccol = mycol;
+        double cval = myval;
+        fetch(q + step);
+        int maxlen = clen;
+        maxlen = max(maxlen, __shfl_xor(maxlen, 8));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
+        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
+        d2v acc = d2v{0.0, 0.0};
+        for (int p = 0; p < maxlen; p += 8) {
+            if (p > 0) {
+                ccol = 0;
+                cval = 0.0;
+                if (p + c < clen) {
+                    ccol = col[ce0 + p + c];
+                    cval = val[ce0 + p + c];
+                }
+            }
+            const int cnt = min(8, maxlen - p);  // wave-uniform; entries past a row's end are (col 0, val 0)
+#pragma unroll 8
             for (int j = 0; j < cnt; ++j) {
-                const int cj = __shfl(mycol, j, 16);
-                const double vj = __shfl(myval, j, 16);
-                acc += vj * X[(int64_t)cj * kW + c];
+                const int cj = __shfl(ccol, j, 8);
+                const double vj = __shfl(cval, j, 8);
+                const d2v x = *reinterpret_cast<const d2v *>(X + (int64_t)cj * kW + 2 * c);
+                acc.x += vj * x.x;
+                acc.y += vj * x.y;
             }
         }
-        Y[r * kW + c] = acc;
+        __builtin_nontemporal_store(acc, reinterpret_cast<d2v *>(Y + r * kW + 2 * c));
     }
 }
 

@@ -2,11 +2,21 @@
 """Condense rocprofv3 CSV output (kernel stats + PMC counter collections) into the
 small text summaries kept under profiles/.
 
-usage: summarize_profile.py <tag> <kernel_stats.csv> [<fetch_counter_collection.csv> <write_counter_collection.csv>]
+usage: summarize_profile.py <tag> <kernel_stats.csv> [<fetch_counter_collection.csv> <write_counter_collection.csv>
+                            [<traffic.json> <workload> <steps> <reorth>]]
+
+With the last four arguments it also writes the per-launch HBM bytes of every kernel class
+(2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) that bench.py reports as roofline.traffic.  For the
+reorthogonalisation kernels only the last steps-1 launches count (those of the timed run; the
+warm-up iterations launched them before with a nearly empty basis).
 """
 import collections
 import csv
+import json
 import sys
+
+CLASS_OF = (("k_spmv", "spmv"), ("k_recur", "recur"), ("k_scale", "scale"), ("k_dots", "dots"),
+            ("k_update", "update"))
 
 
 def short(name):
@@ -37,6 +47,20 @@ def main():
             f = sum(v["f"]) / len(v["f"])
             w = sum(v["w"]) / max(len(v["w"]), 1)
             out.append(f"| {k} | {len(v['f'])} | {f:.0f} | {2*f*1024/1e6:.1f} | {w:.0f} | {w*1024/1e6:.1f} |")
+        if len(sys.argv) >= 9:
+            path, workload, steps, reorth = sys.argv[5], sys.argv[6], int(sys.argv[7]), sys.argv[8]
+            per = {}
+            for k, v in agg.items():
+                cls = next((c for key, c in CLASS_OF if key in k), None)
+                if cls is None or not v["f"] or not v["w"]:
+                    continue
+                f, w = v["f"], v["w"]
+                if cls in ("dots", "update"):
+                    f, w = f[-(steps - 1):], w[-(steps - 1):]
+                per[cls] = 2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w)
+            json.dump({"workload": workload, "steps": steps, "reorth": reorth, "source": tag,
+                       "rule": "2 x FETCH_SIZE + WRITE_SIZE (KiB), averaged per launch; separate --pmc passes",
+                       "bytes_per_launch": per}, open(path, "w"), indent=1)
     print("\n".join(out))
 
 
