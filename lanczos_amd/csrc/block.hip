@@ -49,6 +49,8 @@ struct BlockEngine {
     double *d_small = nullptr;  // G, Rinv, R1, R2: 4 x 256
     double *d_TA = nullptr, *d_TB = nullptr;
     int *d_status = nullptr;
+    int *d_long_rows = nullptr;  // rows with more than kLongRow entries
+    int n_long = 0;
     bool profile = false;
     double prof_ms[LANCZOS_HIP_BK_COUNT] = {0};
     double prof_bytes[LANCZOS_HIP_BK_COUNT] = {0};
@@ -72,6 +74,7 @@ struct BlockEngine {
         (void)hipFree(d_TA);
         (void)hipFree(d_TB);
         (void)hipFree(d_status);
+        (void)hipFree(d_long_rows);
         delete base;
     }
 
@@ -126,7 +129,20 @@ struct BlockEngine {
         HIP_TRY(hipMalloc(&d_TB, sizeof(double) * 256 * (size_t)max_steps));
         HIP_TRY(hipMalloc(&d_status, sizeof(int) * 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int) * 4, stream()));
+        // hub rows get a workgroup each; at most nnz / kLongRow rows can qualify
+        const int cap = (int)std::min<int64_t>(n, base->nnz / kLongRow + 1);
+        HIP_TRY(hipMalloc(&d_long_rows, sizeof(int) * (size_t)cap));
+        const int fb = (int)std::min<int64_t>(groups_spmm, (n + kThreads - 1) / kThreads);
+        if (base->rp64)
+            hipLaunchKernelGGL((k_find_long_rows<int64_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
+                               (const int64_t *)base->d_rp, d_long_rows, cap, d_status + 1);
+        else
+            hipLaunchKernelGGL((k_find_long_rows<int32_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
+                               (const int32_t *)base->d_rp, d_long_rows, cap, d_status + 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&n_long, d_status + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
+        if (n_long > cap) return lz::fail("lanczos_hip_block_create: long-row list overflow (%d > %d)", n_long, cap);
         return 0;
     }
 
@@ -142,6 +158,14 @@ struct BlockEngine {
         else
             hipLaunchKernelGGL((k_spmm16<int32_t>), dim3(groups_spmm), dim3(kThreads), 0, stream(), n, n_pad,
                                (const int32_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+        if (n_long > 0) {
+            if (base->rp64)
+                hipLaunchKernelGGL((k_spmm16_long<int64_t>), dim3(n_long), dim3(kThreads), 0, stream(),
+                                   (const int *)d_long_rows, (const int64_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+            else
+                hipLaunchKernelGGL((k_spmm16_long<int32_t>), dim3(n_long), dim3(kThreads), 0, stream(),
+                                   (const int *)d_long_rows, (const int32_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+        }
         HIP_TRY(hipGetLastError());
         return 0;
     }
@@ -198,7 +222,7 @@ struct BlockEngine {
         HIP_TRY(hipSetDevice(base->device));
         HIP_TRY(hipMemsetAsync(d_Q, 0, sizeof(double) * (size_t)blk_stride * (size_t)(max_steps + 1), stream()));
         HIP_TRY(hipMemcpyAsync(slot(0), x0_host, sizeof(double) * (size_t)n * kW, hipMemcpyHostToDevice, stream()));
-        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int) * 4, stream()));
+        HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), stream()));
         if (int rc = cholqr2(0, nullptr)) return rc;
         HIP_TRY(hipStreamSynchronize(stream()));
         harvest();

@@ -41,6 +41,8 @@ __device__ __forceinline__ double ld_nt(const double *p) { return __builtin_nont
 // ---------------------------------------------------------------------------
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+constexpr int kLongRow = 512;  // rows with more entries go to k_spmm16_long, one workgroup each
+
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
 k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__restrict__ col,
@@ -64,7 +66,8 @@ k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__r
         const int64_t r = qq * 8 + g;
         if (qq < q_hi && r < n) {
             e0 = (int64_t)rp[r];
-            len = (int)((int64_t)rp[r + 1] - e0);
+            const int64_t full = (int64_t)rp[r + 1] - e0;
+            len = full > kLongRow ? -1 : (int)full;  // -1: a long row, left to k_spmm16_long
             if (c < len) {
                 mycol = __builtin_nontemporal_load(col + e0 + c);
                 myval = __builtin_nontemporal_load(val + e0 + c);
@@ -103,7 +106,56 @@ k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__r
                 acc.y += vj * x.y;
             }
         }
-        __builtin_nontemporal_store(acc, reinterpret_cast<d2v *>(Y + r * kW + 2 * c));
+        if (clen >= 0) __builtin_nontemporal_store(acc, reinterpret_cast<d2v *>(Y + r * kW + 2 * c));
+    }
+}
+
+// rows[0 .. count) = the rows with more than kLongRow entries (any order), count[0] their number
+template <typename RP>
+__global__ void __launch_bounds__(kThreads)
+k_find_long_rows(int64_t n, const RP *__restrict__ rp, int *__restrict__ rows, int capacity, int *__restrict__ count) {
+    const int64_t stride = (int64_t)gridDim.x * kThreads;
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < n; r += stride)
+        if ((int64_t)rp[r + 1] - (int64_t)rp[r] > kLongRow) {
+            const int at = atomicAdd(count, 1);
+            if (at < capacity) rows[at] = (int)r;
+        }
+}
+
+// One workgroup per long row (a hub of a power-law graph): its 32 groups of eight lanes take the
+// entries 8 at a time in turn, and the 32 partial rows are added in group order.
+template <typename RP>
+__global__ void __launch_bounds__(kThreads)
+k_spmm16_long(const int *__restrict__ rows, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+              const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y) {
+    __shared__ double part[32][kW];
+    const int r = rows[blockIdx.x];
+    const int c = threadIdx.x & 7, grp = threadIdx.x >> 3;
+    const int64_t e0 = (int64_t)rp[r], e1 = (int64_t)rp[r + 1];
+    d2v acc = d2v{0.0, 0.0};
+    for (int64_t p = e0; p < e1; p += kThreads) {  // uniform over the workgroup
+        int mycol = 0;
+        double myval = 0.0;
+        if (p + threadIdx.x < e1) {
+            mycol = col[p + threadIdx.x];
+            myval = val[p + threadIdx.x];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cj = __shfl(mycol, j, 8);
+            const double vj = __shfl(myval, j, 8);
+            const d2v x = *reinterpret_cast<const d2v *>(X + (int64_t)cj * kW + 2 * c);
+            acc.x += vj * x.x;
+            acc.y += vj * x.y;
+        }
+    }
+    part[grp][2 * c] = acc.x;
+    part[grp][2 * c + 1] = acc.y;
+    __syncthreads();
+    if (threadIdx.x < kW) {
+        double s = 0.0;
+        for (int g = 0; g < 32; ++g) s += part[g][threadIdx.x];
+        Y[(int64_t)r * kW + threadIdx.x] = s;
     }
 }
 

@@ -38,6 +38,45 @@ def test_spmm_matches_oracle(gpu, make):
     assert np.all(np.abs(y[:, 5] - col) <= 1e-14 * bound[:, 5] + 1e-300)
 
 
+def test_spmm_with_empty_and_very_long_rows(gpu):
+    """Ragged rows, empty rows, unsorted duplicate columns, hubs of 600 / 5000 / 40000 entries."""
+    from test_gpu_parity import irregular_matrix
+    a = irregular_matrix(50000, 4, long_rows=((7, 600), (31000, 5000), (49999, 40000), (0, 513)))
+    x = start_block(a.dimension, 12)
+    with la.BlockEngine(a, 2) as e:
+        e.set_block(0, x)
+        e.spmm(0, 1)
+        y = e.get_block(1)
+    want = bl.spmm(a.row_head_indexes, a.column_index, a.values, x)
+    bound = bl.spmm(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x))
+    maxlen = int(np.diff(a.row_head_indexes).max())
+    assert np.all(np.abs(y - want) <= (maxlen + 4) * np.finfo(float).eps * bound + 1e-300)
+    assert np.all(y[np.diff(a.row_head_indexes) == 0] == 0)
+
+
+def test_block_run_on_a_power_law_graph_laplacian(gpu):
+    """R-MAT graph Laplacian (hubs, isolated vertices): the block run against the numpy model, and the
+    single-vector path with full reorthogonalisation (src/lanczos.c:156-167) on the top of the spectrum."""
+    from matrices import rmat_laplacian
+    from test_gpu_parity import crs_from_scipy
+    lap = rmat_laplacian(13)
+    a = crs_from_scipy(-lap)                    # lowest of -L = largest of L: well separated hubs
+    assert int(np.diff(a.row_head_indexes).max()) > 512
+    x0 = start_block(a.dimension, 6)
+    steps = 10
+    ma, mb, _ = bl.block_lanczos(a.row_head_indexes, a.column_index, a.values, x0, steps)
+    with la.BlockEngine(a, steps) as e:
+        e.set_start(x0)
+        e.run(steps)
+        for k in (2, 5, 10):
+            assert rel_err(e.ritz(4, k), bl.ritz(ma, mb, k, 4)) < 1e-10
+        got = e.ritz(3)
+    with la.Engine(a, 121) as e1:
+        e1.set_start_seed(2)
+        alpha, beta = e1.run(120)
+    assert rel_err(got[:3], la.ritz_values(alpha, beta, 120, 3)) < 1e-10
+
+
 @pytest.mark.parametrize("n,nblocks", [(16, 1), (4000, 3), (33333, 11), (70001, 20)])
 def test_projection_kernels_match_numpy(gpu, n, nblocks):
     """H = Q^T W and W -= Q H on arbitrary (non-orthogonal) data: checks the MFMA operand maps."""
