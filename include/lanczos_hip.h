@@ -317,6 +317,21 @@ int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, d
  * runs record the reduced values as the phases consume them). */
 int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_out, int count);
 
+/* ---- thick restart -------------------------------------------------------
+ * No counterpart in the reference, which keeps every vector of a run and stops at max_iter
+ * (src/lanczos.c:58-61, 193).  lanczos_hip_restart replaces the basis v_0..v_k (k iterations
+ * done) by y_i = sum_l coef_host[i * k + l] v_l, i < keep, followed by v_k, and sets the
+ * iteration count to keep; the next step subtracts last_coupling * y_{keep-1} in place of
+ * beta * v_{k-1}.  Needs a mode that reorthogonalises against the whole basis.
+ * lanczos_hip_thick_restart drives whole cycles from a freshly set start vector: fill the basis,
+ * solve the projected problem, stop when the Lanczos residual bounds of the lowest nth pairs are
+ * below tol * ||A|| or after max_cycles, else keep `keep` Ritz vectors and go on.  eig_out[nth];
+ * resid_out[nth], vectors_host[nth][n], cycles_out, products_out may be NULL. */
+int lanczos_hip_restart(lanczos_hip_engine *e, int keep, const double *coef_host, double last_coupling);
+int lanczos_hip_thick_restart(lanczos_hip_engine *e, int nth, int keep, int max_cycles, double tol,
+                              double *eig_out, double *resid_out, double *vectors_host, int *cycles_out,
+                              int *products_out);
+
 /* ---- selective reorthogonalisation: the decision rule on its own --------
  * No counterpart in the reference, whose solvers reorthogonalise by fixed
  * rules (src/lanczos.c:156-167, src/lanczos_cuda.c:679-687).  The tracker
@@ -386,6 +401,9 @@ int lanczos_hip_block_profile(const lanczos_hip_block *b, int cls, double *ms, i
 void lanczos_hip_block_profile_reset(lanczos_hip_block *b);
 /* lowest nth eigenvalues of a dense symmetric n x n matrix (row-major, destroyed) */
 int lanczos_hip_sym_lowest_eigs(double *a, int n, int nth, double *eig);
+/* all eigenpairs of a small dense symmetric matrix (cyclic Jacobi): eig ascending, row i of vec
+ * (n x n) the unit eigenvector of eig[i]; a is destroyed */
+int lanczos_hip_sym_eig_jacobi(double *a, int n, double *eig, double *vec);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,8 @@ _hip.lanczos_hip_run.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
 _hip.lanczos_hip_run.restype = C.c_int
 _hip.lanczos_hip_iterations.argtypes = [C.c_void_p]
 _hip.lanczos_hip_iterations.restype = C.c_int
+_hip.lanczos_hip_thick_restart.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, _dp, _dp, _dp,
+                                           C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _hip.lanczos_hip_reorth_steps.argtypes = [C.c_void_p]
 _hip.lanczos_hip_reorth_steps.restype = C.c_int
 _hip.lanczos_hip_omega_create.argtypes = [C.c_int]
@@ -306,6 +308,19 @@ _hip.lanczos_hip_block_profile_reset.restype = None
 _hip.lanczos_hip_sym_lowest_eigs.argtypes = [_dp, C.c_int, C.c_int, _dp]
 
 
+_hip.lanczos_hip_sym_eig_jacobi.argtypes = [_dp, C.c_int, _dp, _dp]
+
+
+def sym_eig(a: np.ndarray):
+    """All eigenpairs of a small dense symmetric matrix: (values ascending, vectors as rows)."""
+    a = np.array(a, dtype=np.float64, order="C")
+    n = a.shape[0]
+    w, v = np.zeros(n), np.zeros((n, n))
+    if _hip.lanczos_hip_sym_eig_jacobi(a.ctypes.data_as(_dp), n, w.ctypes.data_as(_dp), v.ctypes.data_as(_dp)) != 0:
+        raise LanczosHipError("lanczos_hip_sym_eig_jacobi failed")
+    return w, v
+
+
 def sym_lowest_eigs(a: np.ndarray, nth: int) -> np.ndarray:
     """Lowest nth eigenvalues of a dense symmetric matrix (Householder + bisection, host)."""
     a = np.array(a, dtype=np.float64, order="C")
@@ -508,6 +523,20 @@ class Engine:
     @property
     def iterations(self) -> int:
         return _hip.lanczos_hip_iterations(self._h)
+
+    def thick_restart(self, nth: int, keep: int, max_cycles: int, tol: float, vectors: bool = False):
+        """-> dict(eig, resid, cycles, products[, vectors]) from a freshly set start vector."""
+        eig, resid = np.zeros(nth), np.zeros(nth)
+        vec = np.zeros((nth, self.n)) if vectors else None
+        cycles, products = C.c_int(0), C.c_int(0)
+        _check(_hip.lanczos_hip_thick_restart(self._h, nth, keep, max_cycles, tol, eig.ctypes.data_as(_dp),
+                                              resid.ctypes.data_as(_dp),
+                                              vec.ctypes.data_as(_dp) if vectors else None,
+                                              C.byref(cycles), C.byref(products)), "lanczos_hip_thick_restart")
+        out = {"eig": eig, "resid": resid, "cycles": cycles.value, "products": products.value}
+        if vectors:
+            out["vectors"] = vec
+        return out
 
     @property
     def reorth_steps(self) -> int:

@@ -107,6 +107,8 @@ struct Engine {
     int phase_update(double *red);
     int phase_scale(double *red);
     int enqueue_iteration();
+    int combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld);
+    int restart(int p, const double *coef_host, double last_coupling);
     int selective_tail();
     int run(int steps, double *alpha_out, double *beta_out);
     int spmv_host(const double *x_host, double *y_host);

@@ -660,6 +660,62 @@ int Engine::selective_tail() {
     return launch_scale(norm_parts(k), norm_count);
 }
 
+// out_dev[i * out_ld + .] = sum_{l < m} coef_host[i * m + l] * v_l for i < count: eight at a time,
+// one pass over the basis each.
+int Engine::combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld) {
+    constexpr int J = 8;
+    double *d_coef = nullptr;
+    HIP_TRY(hipMalloc(&d_coef, sizeof(double) * (size_t)m * J));
+    std::vector<double> c((size_t)m * J);
+    int rc = 0;
+    for (int i0 = 0; i0 < count && rc == 0; i0 += J) {
+        const int nj = std::min(J, count - i0);
+        for (int l = 0; l < m; ++l)
+            for (int j = 0; j < J; ++j) c[(size_t)l * J + j] = j < nj ? coef_host[(size_t)(i0 + j) * m + l] : 0.0;
+        hipError_t st = hipMemcpyAsync(d_coef, c.data(), sizeof(double) * c.size(), hipMemcpyHostToDevice, stream);
+        if (st == hipSuccess) {
+            ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (m + nj));
+            hipLaunchKernelGGL((k_combine<J>), dim3(tile_blocks()), dim3(kBlock), 0, stream, (const double2 *)d_V,
+                               ldv / 2, m, (const double *)d_coef, (double2 *)(out_dev + (size_t)i0 * out_ld),
+                               out_ld / 2, nj, ldv / 2);
+            st = hipGetLastError();
+        }
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);  // c is reused by the next group
+        if (st != hipSuccess) rc = fail("lanczos_hip: combine failed: %s", hipGetErrorString(st));
+    }
+    (void)hipFree(d_coef);
+    return rc;
+}
+
+// Thick restart: the basis v_0..v_k becomes y_0..y_{p-1}, v_k with y_i = sum_l coef[i][l] v_l, and
+// the run continues at iteration p.  The next recurrence subtracts last_coupling * y_{p-1} where it
+// would subtract beta * v_{k-1}; the couplings to the other y_i are removed by the
+// reorthogonalisation, which therefore must cover every l < k.
+int Engine::restart(int p, const double *coef_host, double last_coupling) {
+    if (!started) return fail("lanczos_hip_restart: no run to restart");
+    if (reorth != LANCZOS_HIP_REORTH_FULL && reorth != LANCZOS_HIP_REORTH_FULL2 && reorth != LANCZOS_HIP_REORTH_MGS)
+        return fail("lanczos_hip_restart: needs reorthogonalisation against the whole basis (full, full2 or mgs)");
+    if (x_ext) return fail("lanczos_hip_restart: not available on a row-partitioned engine");
+    if (p < 1 || p >= k || !coef_host) return fail("lanczos_hip_restart: keep=%d of %d iterations", p, k);
+    HIP_TRY(hipSetDevice(device));
+    double *d_tmp = nullptr;
+    HIP_TRY(hipMalloc(&d_tmp, sizeof(double) * (size_t)ldv * (size_t)p));
+    int rc = combine(k, p, coef_host, d_tmp, ldv);
+    hipError_t st = hipSuccess;
+    if (rc == 0) st = hipMemcpyAsync(d_V, d_tmp, sizeof(double) * (size_t)ldv * (size_t)p, hipMemcpyDeviceToDevice, stream);
+    if (rc == 0 && st == hipSuccess)
+        st = hipMemcpyAsync(vec(p), vec(k), sizeof(double) * (size_t)ldv, hipMemcpyDeviceToDevice, stream);
+    if (rc == 0 && st == hipSuccess)
+        st = hipMemcpyAsync(d_scal + 1, &last_coupling, sizeof(double), hipMemcpyHostToDevice, stream);
+    if (rc == 0 && st == hipSuccess) st = hipStreamSynchronize(stream);
+    (void)hipFree(d_tmp);
+    if (rc) return rc;
+    if (st != hipSuccess) return fail("lanczos_hip_restart: %s", hipGetErrorString(st));
+    harvest_profile();
+    k = p;
+    return 0;
+}
+
 int Engine::run(int steps, double *alpha_out, double *beta_out) {
     if (steps < 0) return fail("lanczos_hip_run: steps=%d", steps);
     HIP_TRY(hipSetDevice(device));
@@ -819,31 +875,21 @@ int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *e
     if (residual_est)  // |beta_{steps-1} * last component|: the Lanczos bound on ||A y - theta y||
         for (int i = 0; i < m; ++i) residual_est[i] = fabs(b[(size_t)steps - 1] * S[(size_t)i * steps + steps - 1]);
     if (!vectors_host) return 0;
-    double *d_y = nullptr, *d_s = nullptr;
-    int rc = 0;
-    if (hipMalloc(&d_y, sizeof(double) * e->ldv) != hipSuccess || hipMalloc(&d_s, sizeof(double) * steps) != hipSuccess)
-        rc = lz::fail("lanczos_hip_ritz_vectors: out of device memory");
-    for (int i = 0; rc == 0 && i < m; ++i) {
-        // y = sum_j S[i][j] V_j, through the update kernel: 0 - sum_j (-S[i][j]) V_j
-        std::vector<double> neg((size_t)steps);
-        for (int j = 0; j < steps; ++j) neg[(size_t)j] = -S[(size_t)i * steps + j];
-        st = hipMemcpyAsync(d_s, neg.data(), sizeof(double) * steps, hipMemcpyHostToDevice, e->stream);
-        if (st == hipSuccess) st = hipMemsetAsync(d_y, 0, sizeof(double) * e->ldv, e->stream);
-        if (st == hipSuccess) {
-            hipLaunchKernelGGL(lz::k_update, dim3(e->tile_blocks()), dim3(lz::kBlock), 0, e->stream,
-                               (const double2 *)e->d_V, e->ldv / 2, 0, steps, (double2 *)d_y, e->ldv / 2,
-                               (const double *)d_s, e->d_partials);
-            st = hipGetLastError();
-        }
-        if (st == hipSuccess)
-            st = hipMemcpyAsync(vectors_host + (size_t)i * e->n, d_y, sizeof(double) * e->n, hipMemcpyDeviceToHost,
-                                e->stream);
-        if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
-        if (st != hipSuccess) rc = lz::fail("lanczos_hip_ritz_vectors: %s", hipGetErrorString(st));
-    }
+    // y_i = sum_j S[i][j] v_j, eight at a time with one pass over the basis each
+    double *d_y = nullptr;
+    if (hipMalloc(&d_y, sizeof(double) * (size_t)e->ldv * (size_t)m) != hipSuccess)
+        return lz::fail("lanczos_hip_ritz_vectors: out of device memory");
+    int rc = e->combine(steps, m, S.data(), d_y, e->ldv);
+    if (rc == 0 && hipMemcpy2D(vectors_host, sizeof(double) * e->n, d_y, sizeof(double) * e->ldv, sizeof(double) * e->n,
+                               (size_t)m, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = lz::fail("lanczos_hip_ritz_vectors: copy to the host failed");
     (void)hipFree(d_y);
-    (void)hipFree(d_s);
     return rc;
+}
+
+int lanczos_hip_restart(lanczos_hip_engine *e, int keep, const double *coef_host, double last_coupling) {
+    if (!e) return lz::fail("lanczos_hip_restart: NULL handle");
+    return E(e)->restart(keep, coef_host, last_coupling);
 }
 
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e) { return e ? E(e)->spmv_name : ""; }

@@ -819,6 +819,45 @@ k_update(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *_
     if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
 }
 
+// out_j = sum_{l < m} coef[l][j] V_l for j < J: Ritz vectors, or the compressed basis of a thick
+// restart, J at a time with one pass over the basis (the eigenvector product the reference leaves
+// undone behind its `eigenvectors` argument, src/lanczos.h:34-36).  coef is [m][J], zero beyond nout.
+template <int J>
+__global__ void __launch_bounds__(kBlock)
+k_combine(const double2 *__restrict__ V, int64_t ldv2, int m, const double *__restrict__ coef,
+          double2 *__restrict__ out, int64_t out_ld2, int nout, int64_t n2) {
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 acc[J][kEPT2];
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) acc[j][u] = make_double2(0.0, 0.0);
+        const double2 *vl = V + base;
+        for (int l = 0; l < m; ++l, vl += ldv2) {
+            double2 q[kEPT2];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) q[u] = ld_stream(vl + u * kBlock);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const double c = coef[l * J + j];
+#pragma unroll
+                for (int u = 0; u < kEPT2; ++u) {
+                    acc[j][u].x += c * q[u].x;
+                    acc[j][u].y += c * q[u].y;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (j < nout) {  // only the first nout outputs own memory
+#pragma unroll
+                for (int u = 0; u < kEPT2; ++u) out[(int64_t)j * out_ld2 + base + u * kBlock] = acc[j][u];
+            }
+    }
+}
+
 // Matrix statistics for choosing the SpMV form: stats[0] = largest nnz span of a
 // 64-row group, stats[1] / stats[2] = over every `stride`-th row r, the number of
 // entry positions shared with row r+1 / how many of them hold col(r+1,j) == col(r,j)+1.

@@ -68,3 +68,68 @@ int lanczos_hip_sym_lowest_eigs(double *a, int n, int nth, double *eig) {
     free(e);
     return rc;
 }
+
+/* All eigenpairs of a small dense symmetric matrix by cyclic Jacobi rotations
+ * (the projected matrix of a thick-restarted run is an arrowhead joined to a
+ * tridiagonal, of order at most the basis size).  a: n x n row-major,
+ * destroyed; eig ascending; vec row i = unit eigenvector of eig[i]. */
+int lanczos_hip_sym_eig_jacobi(double *a, int n, double *eig, double *vec) {
+    if (!a || !eig || !vec || n < 1) return 1;
+#define A(i, j) a[(size_t)(i) * (size_t)n + (size_t)(j)]
+#define V(i, j) vec[(size_t)(i) * (size_t)n + (size_t)(j)]
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) V(i, j) = (i == j) ? 1.0 : 0.0; /* columns of V^T: row i tracks e_i */
+    double total = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) total += A(i, j) * A(i, j);
+    const double floor_ = total * 1e-34;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int i = 0; i < n; ++i)
+            for (int j = i + 1; j < n; ++j) off += A(i, j) * A(i, j);
+        if (off <= floor_) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const double apq = A(p, q);
+                if (apq == 0.0 || apq * apq < 1e-40 * fabs(A(p, p) * A(q, q)) + 1e-300) continue;
+                const double theta = (A(q, q) - A(p, p)) / (2.0 * apq);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < n; ++k) { /* columns p, q */
+                    const double akp = A(k, p), akq = A(k, q);
+                    A(k, p) = c * akp - s * akq;
+                    A(k, q) = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; ++k) { /* rows p, q */
+                    const double apk = A(p, k), aqk = A(q, k);
+                    A(p, k) = c * apk - s * aqk;
+                    A(q, k) = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; ++k) { /* accumulated rotations, stored transposed */
+                    const double vpk = V(p, k), vqk = V(q, k);
+                    V(p, k) = c * vpk - s * vqk;
+                    V(q, k) = s * vpk + c * vqk;
+                }
+            }
+    }
+    /* sort ascending, rows of vec along */
+    for (int i = 0; i < n; ++i) eig[i] = A(i, i);
+    for (int i = 0; i < n - 1; ++i) {
+        int m = i;
+        for (int j = i + 1; j < n; ++j)
+            if (eig[j] < eig[m]) m = j;
+        if (m != i) {
+            const double t = eig[i];
+            eig[i] = eig[m];
+            eig[m] = t;
+            for (int k = 0; k < n; ++k) {
+                const double u = V(i, k);
+                V(i, k) = V(m, k);
+                V(m, k) = u;
+            }
+        }
+    }
+#undef A
+#undef V
+    return 0;
+}

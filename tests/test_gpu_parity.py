@@ -353,6 +353,40 @@ def test_selective_reorthogonalisation(gpu, tmp_path):
         assert rel_err(la.ritz_values(alpha, beta, k, 4), full.ritz_hist[k - 1]) < 1e-10
 
 
+def test_thick_restart_converges_with_a_small_basis(gpu):
+    """40 basis vectors, restarted: the lowest values of a 60 x 60 grid Laplacian to the closed form and
+    to what an unrestarted run with full reorthogonalisation (src/lanczos.c:156-167) converges to."""
+    a = la.synth_laplacian(2, 60)
+    # the square's second eigenvalue is double; one start vector spans one copy of it, so a run that
+    # stays orthogonal finds the distinct values
+    exact = laplacian_eigs(2, 60, 6)
+    exact = exact[np.concatenate([[True], np.diff(exact) > 1e-9])]
+    v0 = la.gaussian_fill(17, 0, a.dimension)
+    with la.Engine(a, 41) as e:
+        e.set_start(v0)
+        r = e.thick_restart(3, 12, 200, 1e-10, vectors=True)
+    assert 2 <= r["cycles"] < 200 and r["products"] == 40 + (r["cycles"] - 1) * 28
+    assert rel_err(r["eig"], exact[:3]) < 1e-10
+    for i in range(3):
+        y = r["vectors"][i]
+        assert abs(np.linalg.norm(y) - 1) < 1e-10
+        res = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, y) - r["eig"][i] * y
+        assert np.linalg.norm(res) <= r["resid"][i] + 1e-10 * 8
+    with la.Engine(a, 700) as e:
+        e.set_start(v0)
+        alpha, beta = e.run(699)
+    assert rel_err(r["eig"][:2], la.ritz_values(alpha, beta, 699, 2)) < 1e-10
+    # argument checks
+    with la.Engine(a, 41, reorth="none") as e:
+        e.set_start(v0)
+        with pytest.raises(la.LanczosHipError, match="whole basis"):
+            e.thick_restart(3, 12, 5, 1e-8)
+    with la.Engine(a, 10) as e:
+        e.set_start(v0)
+        with pytest.raises(la.LanczosHipError, match="nth <= keep <= max_iter - 3"):
+            e.thick_restart(3, 8, 5, 1e-8)
+
+
 def test_engine_limits(gpu):
     a = la.synth_laplacian(1, 500)
     with la.Engine(a, 5) as e:

@@ -203,3 +203,44 @@ def test_orthogonality_tracker_follows_the_cpu_model():
         t.step(5, 1.0, 1.0)
     # without reorthogonalisation the estimate bounds the real loss: first firing precedes it
     assert none.steps == steps
+
+
+def test_small_dense_symmetric_eigen_solvers_match_numpy():
+    """Host solvers behind the block variant and the thick restart (the reference calls MKL's
+    LAPACKE_dsyevr on its T, src/util.c:118-272): against numpy's LAPACK."""
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 5, 40, 150):
+        a = rng.standard_normal((n, n))
+        a = a + a.T
+        want = np.linalg.eigvalsh(a)
+        nth = min(n, 6)
+        assert np.max(np.abs(la.sym_lowest_eigs(a, nth) - want[:nth])) < 1e-13 * max(1.0, np.abs(want).max()) * n
+        w, v = la.sym_eig(a)
+        assert np.max(np.abs(w - want)) < 1e-12 * max(1.0, np.abs(want).max())
+        assert np.max(np.abs(v @ v.T - np.eye(n))) < 1e-12
+        assert np.max(np.abs(v @ a @ v.T - np.diag(w))) < 1e-11 * max(1.0, np.abs(want).max())
+    # arrowhead joined to a tridiagonal: the projected matrix after a thick restart
+    n, p = 50, 12
+    t = np.diag(rng.standard_normal(n))
+    t[p, :p] = t[:p, p] = rng.standard_normal(p)
+    for i in range(p, n - 1):
+        t[i, i + 1] = t[i + 1, i] = rng.standard_normal()
+    w, v = la.sym_eig(t)
+    assert np.max(np.abs(w - np.linalg.eigvalsh(t))) < 1e-12
+
+
+def test_block_model_reaches_the_closed_form_spectrum():
+    """The numpy model of the block variant on a 2-D grid: orthonormal basis, T = V^T A V, and the
+    lowest values (the double one twice) to the closed form."""
+    from oracle import block_lanczos as bl
+    from matrices import laplacian_eigs
+    a = la.synth_laplacian(2, 20)
+    x0 = la.gaussian_fill(3, 0, a.dimension * 16).reshape(-1, 16)
+    ab, bb, basis = bl.block_lanczos(a.row_head_indexes, a.column_index, a.values, x0, 14)
+    v = np.hstack(basis[:14])
+    assert np.max(np.abs(v.T @ v - np.eye(v.shape[1]))) < 1e-12
+    t = bl.assemble_t(ab, bb, 14)
+    av = bl.spmm(a.row_head_indexes, a.column_index, a.values, v)
+    assert np.max(np.abs(v.T @ av - t)) < 1e-11
+    assert np.max(np.abs(bl.ritz(ab, bb, 14, 3) - laplacian_eigs(2, 20, 3))) < 1e-9
+    assert np.max(np.abs(la.sym_lowest_eigs(t, 5) - np.linalg.eigvalsh(t)[:5])) < 1e-13
