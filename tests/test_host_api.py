@@ -236,11 +236,11 @@ def test_block_model_reaches_the_closed_form_spectrum():
     from matrices import laplacian_eigs
     a = la.synth_laplacian(2, 20)
     x0 = la.gaussian_fill(3, 0, a.dimension * 16).reshape(-1, 16)
-    ab, bb, basis = bl.block_lanczos(a.row_head_indexes, a.column_index, a.values, x0, 14)
-    v = np.hstack(basis[:14])
+    ab, bb, basis = bl.block_lanczos(a.row_head_indexes, a.column_index, a.values, x0, 22)
+    v = np.hstack(basis[:22])
     assert np.max(np.abs(v.T @ v - np.eye(v.shape[1]))) < 1e-12
-    t = bl.assemble_t(ab, bb, 14)
+    t = bl.assemble_t(ab, bb, 22)
     av = bl.spmm(a.row_head_indexes, a.column_index, a.values, v)
     assert np.max(np.abs(v.T @ av - t)) < 1e-11
-    assert np.max(np.abs(bl.ritz(ab, bb, 14, 3) - laplacian_eigs(2, 20, 3))) < 1e-9
+    assert np.max(np.abs(bl.ritz(ab, bb, 22, 3) - laplacian_eigs(2, 20, 3))) < 1e-9
     assert np.max(np.abs(la.sym_lowest_eigs(t, 5) - np.linalg.eigvalsh(t)[:5])) < 1e-13
