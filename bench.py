@@ -51,6 +51,9 @@ def parse_args():
     ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block", action="store_true", help="skip the block-variant section")
+    ap.add_argument("--rand-rows", type=int, default=10_000_000,
+                    help="rows of the random symmetric matrix (~21 entries per row) of the secondary section; "
+                         "50000000 is the full-size configuration, 0 skips the section")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")
@@ -132,6 +135,42 @@ def block_variant(la, a, steps: int = 8) -> dict:
         "vector_steps_per_s": 16 * steps / dt,
         "kernels": kernels,
         "gram_mfma_TFLOPs": 2.0 * n * 256 * gram_blocks / (prof["gram"]["ms"] * 1e-3) / 1e12 if prof["gram"]["ms"] else 0,
+    }
+
+
+def random_symmetric_section(la, torch, rows: int, steps: int = 100) -> dict:
+    """Irregular rows: random symmetric matrix, 10 draws per row mirrored (about 21 entries per row),
+    diagonally dominant.  The SpMV + vector step (no reorthogonalisation) and the SpMV alone, against
+    the same algorithmic bytes as the Laplacian figures."""
+    t0 = time.perf_counter()
+    a = la.synth_random_symmetric(rows, 10, 42)
+    t_gen = time.perf_counter() - t0
+    n, nnz = a.dimension, a.length
+    b = algorithmic_bytes(n, nnz)
+    with la.Engine(a, 4, reorth="none", profile=True) as e:
+        e.set_start_seed(123456789)
+        e.run(5)
+        e.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = e.profile()
+        name = e.spmv_name
+    spmv_gbps = prof["spmv"]["bytes"] / (prof["spmv"]["ms"] * 1e-3) / 1e9
+    return {
+        "workload": f"random symmetric n={n}, nnz={nnz} ({nnz / n:.1f} per row), seed 42",
+        "steps": steps,
+        "iters_per_s": steps / dt,
+        "ms_per_iter": dt / steps * 1e3,
+        "algorithmic_bytes_per_iter": b["iter"],
+        "frac_of_hbm_peak": b["iter"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
+        "spmv_kernel": name,
+        "spmv_avg_ms": prof["spmv"]["ms"] / steps,
+        "spmv_GBps": spmv_gbps,
+        "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
+        "generate_s": t_gen,
     }
 
 
@@ -248,6 +287,8 @@ def single_gpu(args) -> dict:
     out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, K, args.reorth)
     if not args.no_block:
         out["block_variant"] = block_variant(la, a)
+    if args.rand_rows > 0:
+        out["random_symmetric"] = random_symmetric_section(la, torch, args.rand_rows)
     if not args.no_cpu_baseline:
         cb = cpu_baseline(a, v0, args.cpu_steps)
         s = min(cb["steps"], K)

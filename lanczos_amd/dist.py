@@ -374,6 +374,29 @@ def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mo
     return runner
 
 
+def _timed_dist_run(torch, dist, runner, v0, steps, warm):
+    """max over ranks of the wall time of `steps` iterations from the start vector"""
+    runner.set_start(v0)
+    runner.run(warm)
+    runner.set_start(v0)
+    runner.engine.e.profile_reset()
+    torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    runner.run(steps)
+    torch.cuda.synchronize()
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _slab(a, r0, r1, la):
+    """rows r0..r1-1 of a CrsMatrix, columns still global"""
+    h = a.row_head_indexes
+    return la.CrsMatrix(a.values[h[r0]:h[r1]].copy(), a.column_index[h[r0]:h[r1]].copy(), (h[r0:r1 + 1] - h[r0]).copy())
+
+
 def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
     """bench.py for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
@@ -454,6 +477,52 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
             "ritz_lowest4": [float(x) for x in ritz],
         }
+    # ---- the SpMV + vector step on its own (no reorthogonalisation), same slabs
+    steps2 = 100
+    del runner
+    torch.cuda.empty_cache()
+    r2 = build_gpu_rank(la, torch, comm, a_local, bounds, 4, reorth="none", spmv=args.spmv, profile=True)
+    dt2 = _timed_dist_run(torch, dist, r2, v0, steps2, 5)
+    r2.history()                       # drains the stream and collects the kernel timings
+    p2 = r2.engine.e.profile()
+    if rank == 0:
+        b = algorithmic_bytes(n, nnz)
+        out["spmv_vector_step"] = {
+            "iters_per_s": steps2 / dt2,
+            "ms_per_iter": dt2 / steps2 * 1e3,
+            "algorithmic_bytes_per_iter": b["iter"],
+            "frac_of_hbm_peak": b["iter"] * steps2 / dt2 / 1e9 / (hbm_peak * world),
+            "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
+            "exchange": r2.plan.mode,
+        }
+    del r2
+    torch.cuda.empty_cache()
+    # ---- irregular rows: random symmetric matrix, nnz-balanced slabs, all-gather exchange
+    if getattr(args, "rand_rows", 0) > 0:
+        full = la.synth_random_symmetric(args.rand_rows, 10, 42)
+        nr, nnz_r = full.dimension, full.length
+        rb = partition_rows_by_nnz(full.row_head_indexes, world)
+        mine = _slab(full, rb[rank], rb[rank + 1], la)
+        del full
+        r3 = build_gpu_rank(la, torch, comm, mine, rb, 4, reorth="none", spmv=args.spmv, profile=True)
+        v3 = la.gaussian_fill(123456789, rb[rank], rb[rank + 1] - rb[rank])
+        dt3 = _timed_dist_run(torch, dist, r3, v3, steps2, 5)
+        r3.history()
+        p3 = r3.engine.e.profile()
+        if rank == 0:
+            b = algorithmic_bytes(nr, nnz_r)
+            out["random_symmetric"] = {
+                "workload": f"random symmetric n={nr}, nnz={nnz_r} ({nnz_r / nr:.1f} per row), seed 42, "
+                            f"nnz-balanced row slabs over {world} GPUs",
+                "steps": steps2,
+                "iters_per_s": steps2 / dt3,
+                "ms_per_iter": dt3 / steps2 * 1e3,
+                "algorithmic_bytes_per_iter": b["iter"],
+                "frac_of_hbm_peak": b["iter"] * steps2 / dt3 / 1e9 / (hbm_peak * world),
+                "spmv_avg_ms_rank0": p3["spmv"]["ms"] / steps2,
+                "exchange": r3.plan.mode,
+            }
+        del r3
     dist.barrier()
     dist.destroy_process_group()
     return out
