@@ -61,6 +61,12 @@ struct Engine {
     int group = 8;   // lanes per row of the vector kernel
     int log2r = 6;   // log2(rows per wavefront group) of the pipe kernel
     char spmv_name[32] = "";
+    // tiled form of the matrix (LANCZOS_HIP_SPMV_PANEL): entries grouped by (row block, column panel)
+    uint32_t *d_packed = nullptr;    // row in block << 20 | column in panel
+    double *d_pval = nullptr;
+    uint32_t *d_tile_ptr = nullptr;  // [row blocks * panels + 1]
+    int tile_panels = 0, tile_bits = 18, panel_bits = 18;
+    int64_t tile_blocks_n = 0;
     // iteration state
     int k = 0;
     bool started = false;
@@ -82,6 +88,9 @@ struct Engine {
     int upload_crs(const int64_t *rp, const int64_t *ci, const double *va);
     int build_from_coo(const Coo *coo, int64_t length, int swap_row_column);
     int choose_spmv(int requested);
+    int build_panels(int bits);
+    void free_panels();
+    int launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts);
     int alloc_state();
 
     // basis slot of Lanczos vector j (a ring of 3 when nothing older is needed)

@@ -99,7 +99,7 @@ static int read_options(lanczos_hip_options *opt, const lanczos_hip_options *opt
     if (opt_in) memcpy(opt, opt_in, std::min(sizeof(*opt), opt_in->struct_size));
     if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_SELECTIVE)
         return fail("lanczos_hip_create: bad reorth mode %d", opt->reorth);
-    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_ROWS)
+    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_PANEL)
         return fail("lanczos_hip_create: bad spmv_kernel %d", opt->spmv_kernel);
     return 0;
 }
@@ -213,7 +213,7 @@ int Engine::choose_spmv(int requested) {
     spmv_kind = requested;
     // largest nnz span of a 64-row group, and how often neighbouring rows hold
     // neighbouring columns (sampled): what the row-wise gather form needs / likes
-    unsigned long long *d_stats = nullptr, stats[3] = {0, 0, 0};
+    unsigned long long *d_stats = nullptr, stats[5] = {0, 0, 0, 0, 0};
     HIP_TRY(hipMalloc(&d_stats, sizeof(stats)));
     HIP_TRY(hipMemsetAsync(d_stats, 0, sizeof(stats), stream));
     const int64_t stride = std::max<int64_t>(1, (n - 1) / 4096);
@@ -232,9 +232,25 @@ int Engine::choose_spmv(int requested) {
     if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kTile)
         return fail("lanczos_hip_create: the rows SpMV needs every 64-row group to hold <= %d entries (max %lld)",
                     kTile, (long long)max_span);
+    if (const char *s = getenv("LANCZOS_HIP_PANEL_BITS"))
+        if (atoi(s) >= 10 && atoi(s) <= 24) panel_bits = atoi(s);
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) {
         spmv_kind = LANCZOS_HIP_SPMV_PIPE;
-        if (max_span <= kTile && stats[1] > 0 && 2 * stats[2] > stats[1]) spmv_kind = LANCZOS_HIP_SPMV_ROWS;
+        if (max_span <= kTile && stats[1] > 0 && 2 * stats[2] > stats[1]) {
+            spmv_kind = LANCZOS_HIP_SPMV_ROWS;
+        } else {
+            // rows that reach across more of x than the L2s hold (the sampled rows' mean column
+            // extent against 16 MiB of doubles, half the L2s): gathers would each fetch a line from memory
+            const double extent = stats[3] ? (double)stats[4] / (double)stats[3] : 0.0;
+            if (extent * 8.0 > 16.0 * 1048576.0 && mean >= 2.0 && max_span <= 64 * 64) {
+                if (int rc = build_panels(panel_bits)) return rc;
+                if (tile_panels > 0) spmv_kind = LANCZOS_HIP_SPMV_PANEL;
+            }
+        }
+    } else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL) {
+        if (int rc = build_panels(panel_bits)) return rc;
+        if (tile_panels == 0)
+            return fail("lanczos_hip_create: the panel SpMV needs nnz < 2^32 and (row blocks x panels) < 2^32");
     }
     group = pick_group(mean);
     // rows per wavefront group of the pipe kernel: the largest of 64,32,16,8,4,1
@@ -242,7 +258,9 @@ int Engine::choose_spmv(int requested) {
     log2r = 6;
     while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
     if (log2r == 1) log2r = 0;
-    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
+    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
+        snprintf(spmv_name, sizeof(spmv_name), "panel%d", panel_bits);
+    else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
         snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)
         snprintf(spmv_name, sizeof(spmv_name), "pipe%d%s%s", 1 << log2r,
@@ -297,6 +315,7 @@ Engine::~Engine() {
     if (stream) (void)hipStreamSynchronize(stream);
     harvest_profile();
     for (auto ev : event_pool) (void)hipEventDestroy(ev);
+    free_panels();
     (void)hipFree(d_val);
     (void)hipFree(d_col);
     (void)hipFree(d_rp);
@@ -410,6 +429,7 @@ int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *npa
         *nparts = 8;
         return 0;
     }
+    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL) return launch_spmv_panels(x, xdot, y, nparts);
     if (rp64)
         launch_spmv_t<int64_t>(this, x, xdot, y, nparts);
     else

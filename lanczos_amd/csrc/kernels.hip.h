@@ -860,14 +860,15 @@ k_combine(const double2 *__restrict__ V, int64_t ldv2, int m, const double *__re
 
 // Matrix statistics for choosing the SpMV form: stats[0] = largest nnz span of a
 // 64-row group, stats[1] / stats[2] = over every `stride`-th row r, the number of
-// entry positions shared with row r+1 / how many of them hold col(r+1,j) == col(r,j)+1.
+// entry positions shared with row r+1 / how many of them hold col(r+1,j) == col(r,j)+1;
+// stats[3] / stats[4] = sampled non-empty rows / the sum of their column extents (max - min).
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
 k_row_stats(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, int64_t stride,
             unsigned long long *__restrict__ stats) {
     const int64_t groups = (n + 63) >> 6;
     const int64_t step = (int64_t)gridDim.x * kBlock;
-    unsigned long long span = 0, pairs = 0, alike = 0;
+    unsigned long long span = 0, pairs = 0, alike = 0, rows = 0, width = 0;
     for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += step) {
         const int64_t r1 = (g + 1) * 64 < n ? (g + 1) * 64 : n;
         const unsigned long long s = (unsigned long long)(rp[r1] - rp[g * 64]);
@@ -881,10 +882,23 @@ k_row_stats(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
             pairs++;
             alike += (col[a1 + j] == col[a0 + j] + 1);
         }
+        if (a1 > a0) {  // stats[3], stats[4]: sampled rows and the sum of their column extents
+            int lo = col[a0], hi = lo;
+            const RP end = (a1 - a0) > 4096 ? a0 + 4096 : a1;
+            for (RP j = a0 + 1; j < end; ++j) {
+                const int c = col[j];
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
+            rows++;
+            width += (unsigned long long)(hi - lo);
+        }
     }
     if (span) atomicMax(&stats[0], span);
     if (pairs) atomicAdd(&stats[1], pairs);
     if (alike) atomicAdd(&stats[2], alike);
+    if (rows) atomicAdd(&stats[3], rows);
+    if (width) atomicAdd(&stats[4], width);
 }
 
 // 64-bit column indices -> 32-bit (matrix upload)

@@ -128,6 +128,51 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
         la.Engine(big, 3, spmv="rows")
 
 
+def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
+    """Column-panel form: same products as the row-wise oracle (src/crs.c:155-178) whatever the panel
+    width, the same Lanczos sequences, bitwise repeatable, dense rows included."""
+    a = la.synth_random_symmetric(30000, 10, 9)
+    x = np.random.default_rng(3).standard_normal(a.dimension)
+    want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+    for bits in ("10", "12", "18"):
+        monkeypatch.setenv("LANCZOS_HIP_PANEL_BITS", bits)
+        with la.Engine(a, 21, spmv="panel") as e:
+            assert e.spmv_name == "panel" + bits
+            y = e.spmv(x)
+            assert np.all(np.abs(y - want) <= spmv_tolerance(a, x))
+            assert e.spmv(x).tobytes() == y.tobytes()
+            v0 = la.gaussian_fill(5, 0, a.dimension)
+            e.set_start(v0)
+            alpha, beta = e.run(20)
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 21, 0.0)
+        assert rel_err(alpha, o.alpha) < 1e-12 and rel_err(beta, o.beta) < 1e-12
+    monkeypatch.delenv("LANCZOS_HIP_PANEL_BITS")
+    # ragged rows, empty rows, duplicates
+    b = irregular_matrix(20000, 8)
+    xb = np.random.default_rng(4).standard_normal(b.dimension)
+    monkeypatch.setenv("LANCZOS_HIP_PANEL_BITS", "11")
+    with la.Engine(b, 3, spmv="panel") as e:
+        yb = e.spmv(xb)
+    assert np.all(np.abs(yb - oracle.matvec_crs(b.row_head_indexes, b.column_index, b.values, xb))
+                  <= spmv_tolerance(b, xb))
+    dense = irregular_matrix(20000, 8, long_rows=((5, 9000), (19999, 300)))
+    with la.Engine(dense, 3, spmv="panel") as e:
+        yd = e.spmv(xb)
+    assert np.all(np.abs(yd - oracle.matvec_crs(dense.row_head_indexes, dense.column_index, dense.values, xb))
+                  <= spmv_tolerance(dense, xb))
+    monkeypatch.delenv("LANCZOS_HIP_PANEL_BITS")
+    # chosen by itself when the rows reach across more of x than the L2s hold
+    big = la.synth_random_symmetric(5_000_000, 4, 1)
+    with la.Engine(big, 3, reorth="none") as e:
+        assert e.spmv_name.startswith("panel")
+        xg = la.gaussian_fill(7, 0, big.dimension)
+        yg = e.spmv(xg)
+    assert np.all(np.abs(yg - oracle.matvec_crs(big.row_head_indexes, big.column_index, big.values, xg))
+                  <= spmv_tolerance(big, xg))
+    with la.Engine(la.synth_laplacian(3, 64), 3) as e:
+        assert e.spmv_name.startswith("rows")
+
+
 def test_device_coo_to_crs_is_bit_exact(gpu, golden_dir):
     """Device build against the reference's own crs.c output and against the host build."""
     from test_oracle_golden import CASES, read_ref_bin
