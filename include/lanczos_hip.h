@@ -116,10 +116,11 @@ enum {
     LANCZOS_HIP_SPMV_STREAM = 2, /* one wavefront per group of 64 rows, nnz streamed through LDS */
     LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups */
     LANCZOS_HIP_SPMV_PIPE_NT = 4, /* pipe form with non-temporal col/val loads */
-    LANCZOS_HIP_SPMV_PANEL = 6,  /* column panels the size of an L2 share: for matrices whose rows reach all
-                                    over a vector too large for the caches (random sparsity), the entries
-                                    are regrouped by column panel and the product runs panel by panel,
-                                    y accumulating, so every gather hits L2 */
+    LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
+                                    caches (random sparsity): entries regrouped on the device by
+                                    (block of 4096 rows, column panel of 2^18 columns); a workgroup keeps
+                                    its rows of y in LDS and sweeps the panels, whose slice of x stays in
+                                    L2.  LANCZOS_HIP_PANEL_BITS overrides the panel width. */
     LANCZOS_HIP_SPMV_ROWS = 5    /* pipe form whose gathers run row-wise (coalesced for stencil-like
                                     matrices); needs every 64-row group to hold <= 512 entries */
 };
