@@ -121,6 +121,10 @@ enum {
                                     (block of 4096 rows, column panel of 2^18 columns); a workgroup keeps
                                     its rows of y in LDS and sweeps the panels, whose slice of x stays in
                                     L2.  LANCZOS_HIP_PANEL_BITS overrides the panel width. */
+    LANCZOS_HIP_SPMV_DICT = 7,   /* dictionary of row patterns ((col - row, value) lists): one 16-bit pattern
+                                    number per row replaces the row's entries; for matrices whose rows
+                                    repeat (stencils on grids), at most 65535 patterns of at most 32
+                                    entries, found and verified entry by entry on the device */
     LANCZOS_HIP_SPMV_ROWS = 5    /* pipe form whose gathers run row-wise (coalesced for stencil-like
                                     matrices); needs every 64-row group to hold <= 512 entries */
 };

@@ -1,0 +1,366 @@
+// SpMV through a dictionary of row patterns, for matrices whose rows repeat
+// (stencils on structured grids: the reference's own test matrices are 1-D, 2-D
+// and 3-D Laplacians).  A row's pattern is its entries written relative to the
+// row: ((col - row), value) in order.  The 256^3 7-point Laplacian has 27
+// distinct patterns among 16.7 M rows.  The matrix then is one 16-bit pattern
+// number per row plus the dictionary, and
+//     y[r] = sum_j dict_val[p][j] * x[r + dict_off[p][j]],  p = pattern[r]
+// reads 2 bytes per row instead of 12 bytes per entry (src/crs.c:155-178 reads
+// 16).  The entries are taken in their CRS order, so y is bit for bit what the
+// row-wise kernel computes.  The dictionary is found on the device (hash per
+// row, sort, unique) and every row is then compared entry by entry with its
+// pattern: a hash collision cannot slip through.
+#include <hipcub/hipcub.hpp>
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "engine.h"
+
+namespace lz {
+
+static constexpr int kBlock = 256;
+static constexpr int kDictMaxLen = 32;       // longest row a pattern may have
+static constexpr int kDictMaxPatterns = 65535;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_row_hash(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, const double *__restrict__ val,
+           uint64_t *__restrict__ hash, int *__restrict__ too_long) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step) {
+        const int64_t a = (int64_t)rp[r], b = (int64_t)rp[r + 1];
+        if (b - a > kDictMaxLen) {
+            *too_long = 1;
+            hash[r] = 0;
+            continue;
+        }
+        uint64_t h = mix64((uint64_t)(b - a));
+        for (int64_t e = a; e < b; ++e) {
+            h = mix64(h ^ (uint64_t)(uint32_t)(col[e] - (int32_t)r));
+            h = mix64(h ^ (uint64_t)__double_as_longlong(val[e]));
+        }
+        hash[r] = h;
+    }
+}
+
+// pattern[r] = index of hash[r] among the sorted distinct hashes; rep[p] = lowest row with pattern p
+__global__ void __launch_bounds__(kBlock)
+k_dict_assign(int64_t n, const uint64_t *__restrict__ hash, const uint64_t *__restrict__ uniq, int count,
+              uint16_t *__restrict__ pattern, int *__restrict__ rep) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step) {
+        const uint64_t h = hash[r];
+        int lo = 0, hi = count;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (uniq[mid] < h) lo = mid + 1;
+            else hi = mid;
+        }
+        pattern[r] = (uint16_t)lo;
+        atomicMin(&rep[lo], (int)r);
+    }
+}
+
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_dict_fill(int count, const int *__restrict__ rep, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+            const double *__restrict__ val, int stride, int32_t *__restrict__ dlen, int32_t *__restrict__ doff,
+            double *__restrict__ dval) {
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= count) return;
+    const int r = rep[p];
+    const int64_t a = (int64_t)rp[r];
+    const int len = (int)((int64_t)rp[r + 1] - a);
+    dlen[p] = len;
+    for (int j = 0; j < stride; ++j) {
+        doff[p * stride + j] = j < len ? col[a + j] - r : 0;
+        dval[p * stride + j] = j < len ? val[a + j] : 0.0;
+    }
+}
+
+// every row against its pattern, entry by entry
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_dict_verify(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, const double *__restrict__ val,
+              const uint16_t *__restrict__ pattern, int stride, const int32_t *__restrict__ dlen,
+              const int32_t *__restrict__ doff, const double *__restrict__ dval, int *__restrict__ mismatch) {
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step) {
+        const int p = pattern[r];
+        const int64_t a = (int64_t)rp[r];
+        const int len = (int)((int64_t)rp[r + 1] - a);
+        bool ok = len == dlen[p];
+        for (int j = 0; ok && j < len; ++j)
+            ok = (col[a + j] - (int32_t)r == doff[p * stride + j]) &&
+                 (__double_as_longlong(val[a + j]) == __double_as_longlong(dval[p * stride + j]));
+        if (!ok) *mismatch = 1;
+    }
+}
+
+// One lane per row, 64 consecutive rows per wavefront, kDictRows rows per thread.  The dictionary
+// sits in LDS when it fits (LDS_DICT).  A workgroup step covers kSpan consecutive rows and first
+// copies x[first row - halo .. last row + halo] into LDS with coalesced loads, each memory line once;
+// entries whose column offset lies within the halo read that window, only the far ones (the
+// +-N^2 neighbours of a 3-D grid) go to memory, again one line once per step.  This matters more
+// than the bytes: the vector L1 handles requests in order and stalls on a second touch of a line
+// whose fill is still in flight, which is what the overlapping gathers of a stencil produce
+// (measured: the L1 sat in that stall 70 % of the time with direct gathers).
+// Workgroup b serves the b % 8-th eighth of the rows (b and b + 8 share an L2).
+// partials[b] = this workgroup's part of xdot . y.
+constexpr int kDictRows = 4;
+constexpr int kDictLdsEntries = 1024;  // dictionary entries (pattern x position) copied to LDS (12 KiB)
+constexpr int kDictSpan = kBlock * kDictRows;
+constexpr int kDictMaxHalo = 2048;
+
+template <bool LDS_DICT>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_dict(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
+            const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
+            const double *__restrict__ x, const double *__restrict__ xdot, double *__restrict__ y,
+            double *__restrict__ partials) {
+    extern __shared__ double win[];  // kDictSpan + 2 * halo doubles, then (LDS_DICT) the dictionary
+    __shared__ double red[kBlock / 64];
+    double *s_val = win + kDictSpan + 2 * halo;
+    int32_t *s_off = reinterpret_cast<int32_t *>(s_val + patterns * stride);
+    int32_t *s_len = s_off + patterns * stride;
+    if (LDS_DICT) {
+        for (int i = threadIdx.x; i < patterns * stride; i += kBlock) {
+            s_val[i] = dval[i];
+            s_off[i] = doff[i];
+        }
+        for (int i = threadIdx.x; i < patterns; i += kBlock) s_len[i] = dlen[i];
+    }
+    const double *tv = LDS_DICT ? s_val : dval;
+    const int32_t *to = LDS_DICT ? s_off : doff;
+    const int32_t *tl = LDS_DICT ? s_len : dlen;
+    const int wlen = kDictSpan + 2 * halo;
+    const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
+    const int64_t per_xcd = (chunks + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > chunks) c_end = chunks;
+    double acc = 0.0;
+    for (int64_t c = xcd * per_xcd + slot; c < c_end; c += slots) {
+        const int64_t row0 = c * kDictSpan;
+        __syncthreads();  // the previous step's readers are done (and the dictionary copy is complete)
+        for (int i = threadIdx.x; i < wlen; i += kBlock) {
+            const int64_t g = row0 - halo + i;
+            win[i] = (g >= 0 && g < n_ext) ? x[g] : 0.0;
+        }
+
+        int p[kDictRows], len[kDictRows];
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            const int64_t r = row0 + u * kBlock + threadIdx.x;
+            p[u] = r < n ? (int)pattern[r] : -1;
+        }
+        __syncthreads();
+        int maxlen = 0;
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            len[u] = p[u] >= 0 ? tl[p[u]] : 0;
+            maxlen = max(maxlen, len[u]);
+        }
+        double sum[kDictRows];
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) sum[u] = 0.0;
+        for (int j = 0; j < maxlen; ++j) {
+#pragma unroll
+            for (int u = 0; u < kDictRows; ++u)
+                if (j < len[u]) {
+                    const int off = to[p[u] * stride + j];
+                    const int local = u * kBlock + (int)threadIdx.x;
+                    const double xv = (off >= -halo && off <= halo) ? win[local + halo + off] : x[row0 + local + off];
+                    sum[u] += tv[p[u] * stride + j] * xv;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u)
+            if (p[u] >= 0) {
+                const int64_t r = row0 + u * kBlock + threadIdx.x;
+                __builtin_nontemporal_store(sum[u], y + r);
+                acc += (xdot == x ? win[u * kBlock + (int)threadIdx.x + halo] : xdot[r]) * sum[u];
+            }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+void Engine::free_dict() {
+    (void)hipFree(d_pattern);
+    (void)hipFree(d_dlen);
+    (void)hipFree(d_doff);
+    (void)hipFree(d_dval);
+    d_pattern = nullptr;
+    d_dlen = nullptr;
+    d_doff = nullptr;
+    d_dval = nullptr;
+    dict_patterns = 0;
+}
+
+// dict_patterns > 0 afterwards when the matrix is a dictionary of at most 65535 row patterns of at
+// most 32 entries; 0 when it is not.  Non-zero return on errors.
+int Engine::build_dict() {
+    free_dict();
+    if (nnz == 0) return 0;
+    uint64_t *d_hash = nullptr, *d_sorted = nullptr, *d_uniq = nullptr;
+    int *d_flags = nullptr, *d_count = nullptr, *d_rep = nullptr;
+    void *d_tmp = nullptr, *d_tmp2 = nullptr;
+    auto cleanup = [&]() {
+        (void)hipFree(d_hash);
+        (void)hipFree(d_sorted);
+        (void)hipFree(d_uniq);
+        (void)hipFree(d_flags);
+        (void)hipFree(d_count);
+        (void)hipFree(d_rep);
+        (void)hipFree(d_tmp);
+        (void)hipFree(d_tmp2);
+    };
+#define DC_TRY(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t st__ = (call);                                                                      \
+        if (st__ != hipSuccess) {                                                                      \
+            cleanup();                                                                                 \
+            free_dict();                                                                               \
+            return fail("HIP API failed at %s:%d with error: %s (%d)", __FILE__, __LINE__,            \
+                        hipGetErrorString(st__), (int)st__);                                           \
+        }                                                                                              \
+    } while (0)
+    DC_TRY(hipMalloc(&d_hash, sizeof(uint64_t) * n));
+    DC_TRY(hipMalloc(&d_flags, sizeof(int) * 2));
+    DC_TRY(hipMemsetAsync(d_flags, 0, sizeof(int) * 2, stream));
+    const int rblocks = (int)std::min<int64_t>(max_blocks, (n + kBlock - 1) / kBlock);
+    if (rp64)
+        hipLaunchKernelGGL((k_row_hash<int64_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int64_t *)d_rp,
+                           (const int32_t *)d_col, (const double *)d_val, d_hash, d_flags);
+    else
+        hipLaunchKernelGGL((k_row_hash<int32_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int32_t *)d_rp,
+                           (const int32_t *)d_col, (const double *)d_val, d_hash, d_flags);
+    DC_TRY(hipGetLastError());
+    int flags[2] = {0, 0};
+    DC_TRY(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+    DC_TRY(hipStreamSynchronize(stream));
+    if (flags[0]) {  // a row longer than a pattern may be
+        cleanup();
+        return 0;
+    }
+    DC_TRY(hipMalloc(&d_sorted, sizeof(uint64_t) * n));
+    DC_TRY(hipMalloc(&d_uniq, sizeof(uint64_t) * n));
+    DC_TRY(hipMalloc(&d_count, sizeof(int)));
+    size_t tmp_bytes = 0;
+    DC_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, tmp_bytes, d_hash, d_sorted, (int)n, 0, 64, stream));
+    DC_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+    DC_TRY(hipcub::DeviceRadixSort::SortKeys(d_tmp, tmp_bytes, d_hash, d_sorted, (int)n, 0, 64, stream));
+    size_t tmp2_bytes = 0;
+    DC_TRY(hipcub::DeviceSelect::Unique(nullptr, tmp2_bytes, d_sorted, d_uniq, d_count, (int)n, stream));
+    DC_TRY(hipMalloc(&d_tmp2, tmp2_bytes ? tmp2_bytes : 1));
+    DC_TRY(hipcub::DeviceSelect::Unique(d_tmp2, tmp2_bytes, d_sorted, d_uniq, d_count, (int)n, stream));
+    int count = 0;
+    DC_TRY(hipMemcpyAsync(&count, d_count, sizeof(int), hipMemcpyDeviceToHost, stream));
+    DC_TRY(hipStreamSynchronize(stream));
+    if (count < 1 || count > kDictMaxPatterns) {
+        cleanup();
+        return 0;
+    }
+    DC_TRY(hipMalloc(&d_pattern, sizeof(uint16_t) * n));
+    DC_TRY(hipMalloc(&d_rep, sizeof(int) * count));
+    DC_TRY(hipMemsetAsync(d_rep, 0x7F, sizeof(int) * count, stream));
+    hipLaunchKernelGGL(k_dict_assign, dim3(rblocks), dim3(kBlock), 0, stream, n, (const uint64_t *)d_hash,
+                       (const uint64_t *)d_uniq, count, d_pattern, d_rep);
+    // dictionary rows as long as the longest row of the matrix (known from the 64-row spans only as
+    // a bound, so measured here: the largest length among the representatives)
+    std::vector<int> rep_host((size_t)count);
+    DC_TRY(hipMemcpyAsync(rep_host.data(), d_rep, sizeof(int) * count, hipMemcpyDeviceToHost, stream));
+    DC_TRY(hipStreamSynchronize(stream));
+    int stride = 1;
+    for (int p = 0; p < count; ++p) {
+        int64_t ab[2] = {0, 0};
+        if (rp64) {
+            DC_TRY(hipMemcpy(ab, (const int64_t *)d_rp + rep_host[(size_t)p], sizeof(ab), hipMemcpyDeviceToHost));
+        } else {
+            int32_t t[2] = {0, 0};
+            DC_TRY(hipMemcpy(t, (const int32_t *)d_rp + rep_host[(size_t)p], sizeof(t), hipMemcpyDeviceToHost));
+            ab[0] = t[0];
+            ab[1] = t[1];
+        }
+        stride = std::max(stride, (int)(ab[1] - ab[0]));
+    }
+    DC_TRY(hipMalloc(&d_dlen, sizeof(int32_t) * count));
+    DC_TRY(hipMalloc(&d_doff, sizeof(int32_t) * (size_t)count * stride));
+    DC_TRY(hipMalloc(&d_dval, sizeof(double) * (size_t)count * stride));
+    const int pblocks = (count + kBlock - 1) / kBlock;
+    if (rp64) {
+        hipLaunchKernelGGL((k_dict_fill<int64_t>), dim3(pblocks), dim3(kBlock), 0, stream, count, (const int *)d_rep,
+                           (const int64_t *)d_rp, (const int32_t *)d_col, (const double *)d_val, stride, d_dlen, d_doff,
+                           d_dval);
+        hipLaunchKernelGGL((k_dict_verify<int64_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int64_t *)d_rp,
+                           (const int32_t *)d_col, (const double *)d_val, (const uint16_t *)d_pattern, stride,
+                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval, d_flags + 1);
+    } else {
+        hipLaunchKernelGGL((k_dict_fill<int32_t>), dim3(pblocks), dim3(kBlock), 0, stream, count, (const int *)d_rep,
+                           (const int32_t *)d_rp, (const int32_t *)d_col, (const double *)d_val, stride, d_dlen, d_doff,
+                           d_dval);
+        hipLaunchKernelGGL((k_dict_verify<int32_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int32_t *)d_rp,
+                           (const int32_t *)d_col, (const double *)d_val, (const uint16_t *)d_pattern, stride,
+                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval, d_flags + 1);
+    }
+    DC_TRY(hipGetLastError());
+    DC_TRY(hipMemcpyAsync(flags, d_flags, sizeof(flags), hipMemcpyDeviceToHost, stream));
+    // the dictionary's column offsets within reach set the halo of the LDS window; the far ones
+    // (the +-N^2 neighbours of a 3-D grid) are gathered from memory (LDS windows for them were tried
+    // and were slower: more LDS traffic and fewer resident workgroups)
+    std::vector<int32_t> hlen((size_t)count), hoff((size_t)count * stride);
+    DC_TRY(hipMemcpyAsync(hlen.data(), d_dlen, sizeof(int32_t) * count, hipMemcpyDeviceToHost, stream));
+    DC_TRY(hipMemcpyAsync(hoff.data(), d_doff, sizeof(int32_t) * hoff.size(), hipMemcpyDeviceToHost, stream));
+    DC_TRY(hipStreamSynchronize(stream));
+    cleanup();
+#undef DC_TRY
+    dict_halo = 0;
+    for (int p = 0; p < count; ++p)
+        for (int j = 0; j < hlen[(size_t)p]; ++j) {
+            const int off = hoff[(size_t)p * stride + j], mag = off < 0 ? -off : off;
+            if (mag <= kDictMaxHalo) dict_halo = std::max(dict_halo, mag);
+        }
+    if (flags[1]) {  // two different rows behind one hash: keep the CRS kernels
+        free_dict();
+        return 0;
+    }
+    dict_patterns = count;
+    dict_stride = stride;
+    return 0;
+}
+
+int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts) {
+    const int64_t chunks = (n + kBlock * kDictRows - 1) / (kBlock * kDictRows);
+    int blocks = (int)std::min<int64_t>(max_blocks, (chunks + 7) / 8 * 8);
+    *nparts = blocks;
+    size_t win_bytes = sizeof(double) * (size_t)(kDictSpan + 2 * dict_halo);
+    if (dict_patterns * dict_stride <= kDictLdsEntries)
+        win_bytes += (size_t)dict_patterns * dict_stride * 12 + (size_t)dict_patterns * 4;
+    if (dict_patterns * dict_stride <= kDictLdsEntries)
+        hipLaunchKernelGGL((k_spmv_dict<true>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
+                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
+                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials);
+    else
+        hipLaunchKernelGGL((k_spmv_dict<false>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
+                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
+                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials);
+    const hipError_t st = hipGetLastError();
+    if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
+    return 0;
+}
+
+}  // namespace lz

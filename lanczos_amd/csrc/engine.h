@@ -67,6 +67,11 @@ struct Engine {
     uint32_t *d_tile_ptr = nullptr;  // [row blocks * panels + 1]
     int tile_panels = 0, tile_bits = 18, panel_bits = 18;
     int64_t tile_blocks_n = 0;
+    // dictionary form of the matrix (LANCZOS_HIP_SPMV_DICT): one pattern number per row
+    uint16_t *d_pattern = nullptr;
+    int32_t *d_dlen = nullptr, *d_doff = nullptr;  // [patterns], [patterns][dict_stride]
+    double *d_dval = nullptr;
+    int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
     // iteration state
     int k = 0;
     bool started = false;
@@ -88,6 +93,9 @@ struct Engine {
     int upload_crs(const int64_t *rp, const int64_t *ci, const double *va);
     int build_from_coo(const Coo *coo, int64_t length, int swap_row_column);
     int choose_spmv(int requested);
+    int build_dict();
+    void free_dict();
+    int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts);
     int build_panels(int bits);
     void free_panels();
     int launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts);

@@ -99,7 +99,7 @@ static int read_options(lanczos_hip_options *opt, const lanczos_hip_options *opt
     if (opt_in) memcpy(opt, opt_in, std::min(sizeof(*opt), opt_in->struct_size));
     if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_SELECTIVE)
         return fail("lanczos_hip_create: bad reorth mode %d", opt->reorth);
-    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_PANEL)
+    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_DICT)
         return fail("lanczos_hip_create: bad spmv_kernel %d", opt->spmv_kernel);
     return 0;
 }
@@ -234,6 +234,18 @@ int Engine::choose_spmv(int requested) {
                     kTile, (long long)max_span);
     if (const char *s = getenv("LANCZOS_HIP_PANEL_BITS"))
         if (atoi(s) >= 10 && atoi(s) <= 24) panel_bits = atoi(s);
+    const bool no_dict = getenv("LANCZOS_HIP_NO_DICT") && atoi(getenv("LANCZOS_HIP_NO_DICT")) != 0;
+    if (spmv_kind == LANCZOS_HIP_SPMV_AUTO && !no_dict && stats[1] > 0 && 2 * stats[2] > stats[1]) {
+        // neighbouring rows hold neighbouring columns: rows are likely to repeat as patterns
+        if (int rc = build_dict()) return rc;
+        if (dict_patterns > 0) spmv_kind = LANCZOS_HIP_SPMV_DICT;
+    }
+    if (spmv_kind == LANCZOS_HIP_SPMV_DICT && dict_patterns == 0) {
+        if (int rc = build_dict()) return rc;
+        if (dict_patterns == 0)
+            return fail("lanczos_hip_create: the dictionary SpMV needs rows of at most 32 entries that repeat as at "
+                        "most 65535 distinct (column offset, value) patterns");
+    }
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) {
         spmv_kind = LANCZOS_HIP_SPMV_PIPE;
         if (max_span <= kTile && stats[1] > 0 && 2 * stats[2] > stats[1]) {
@@ -258,7 +270,9 @@ int Engine::choose_spmv(int requested) {
     log2r = 6;
     while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
     if (log2r == 1) log2r = 0;
-    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
+    if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
+        snprintf(spmv_name, sizeof(spmv_name), "dict%d", dict_patterns);
+    else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
         snprintf(spmv_name, sizeof(spmv_name), "panel%d", panel_bits);
     else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
         snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
@@ -316,6 +330,7 @@ Engine::~Engine() {
     harvest_profile();
     for (auto ev : event_pool) (void)hipEventDestroy(ev);
     free_panels();
+    free_dict();
     (void)hipFree(d_val);
     (void)hipFree(d_col);
     (void)hipFree(d_rp);
@@ -349,6 +364,8 @@ int Engine::tile_blocks() const {
 }
 
 double Engine::spmv_bytes() const {
+    if (spmv_kind == LANCZOS_HIP_SPMV_DICT)  // what this format reads and writes: pattern numbers, x, y
+        return 2.0 * (double)n + 8.0 * (double)n_ext + 8.0 * (double)n + 12.0 * (double)dict_patterns * dict_stride;
     return 12.0 * (double)nnz + (rp64 ? 8.0 : 4.0) * (double)(n + 1) + 8.0 * (double)n_ext + 8.0 * (double)n;
 }
 
@@ -429,6 +446,7 @@ int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *npa
         *nparts = 8;
         return 0;
     }
+    if (spmv_kind == LANCZOS_HIP_SPMV_DICT) return launch_spmv_dict(x, xdot, y, nparts);
     if (spmv_kind == LANCZOS_HIP_SPMV_PANEL) return launch_spmv_panels(x, xdot, y, nparts);
     if (rp64)
         launch_spmv_t<int64_t>(this, x, xdot, y, nparts);

@@ -91,7 +91,7 @@ def test_power_law_graph_laplacian(gpu, kind):
     assert np.max(np.abs(ritz - o.eigenvalues)) < 1e-10 * tnorm
 
 
-def test_spmv_zero_matrix_and_auto_kernel(gpu):
+def test_spmv_zero_matrix_and_auto_kernel(gpu, monkeypatch):
     n = 300
     a = la.CrsMatrix(np.zeros(0), np.zeros(0, np.int64), np.zeros(n + 1, np.int64))
     with la.Engine(a, 3) as e:
@@ -103,7 +103,11 @@ def test_spmv_zero_matrix_and_auto_kernel(gpu):
         want = oracle.matvec_crs(r.row_head_indexes, r.column_index, r.values, x)
         assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(r, x))
     with la.Engine(la.synth_laplacian(3, 16), 3) as e:
+        assert e.spmv_name == "dict27"           # a cube's rows: interior, 6 faces, 12 edges, 8 corners
+    monkeypatch.setenv("LANCZOS_HIP_NO_DICT", "1")
+    with la.Engine(la.synth_laplacian(3, 16), 3) as e:
         assert e.spmv_name == "rows64"           # stencil: neighbouring rows hold neighbouring columns
+    monkeypatch.delenv("LANCZOS_HIP_NO_DICT")
     with la.Engine(la.synth_laplacian(3, 16), 3, spmv="pipe") as e:
         assert e.spmv_name == "pipe64"
 
@@ -126,6 +130,40 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
     big = irregular_matrix(1000, 3, ((0, 2000),))
     with pytest.raises(la.LanczosHipError, match="rows SpMV needs"):
         la.Engine(big, 3, spmv="rows")
+
+
+def test_dictionary_spmv_on_repeating_rows(gpu):
+    """One pattern number per row: the same bits as the row-wise kernel (entries in CRS order,
+    src/crs.c:172-175), the Lanczos sequences of the oracle, and a clean refusal when rows do not repeat."""
+    for a in (la.synth_laplacian(1, 5000), la.synth_laplacian(2, 70), la.synth_laplacian(3, 21)):
+        x = np.random.default_rng(1).standard_normal(a.dimension)
+        with la.Engine(a, 31, spmv="dict") as e:
+            assert e.spmv_name.startswith("dict")
+            y = e.spmv(x)
+            v0 = la.gaussian_fill(3, 0, a.dimension)
+            e.set_start(v0)
+            alpha, beta = e.run(30)
+        with la.Engine(a, 3, spmv="rows") as e:
+            assert e.spmv(x).tobytes() == y.tobytes()
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        assert np.all(np.abs(y - want) <= spmv_tolerance(a, x))
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 31, 0.0)
+        assert rel_err(alpha, o.alpha) < 1e-12 and rel_err(beta, o.beta) < 1e-12
+    # a stencil with a few perturbed entries and one changed row: still a dictionary, a larger one
+    a = la.synth_laplacian(2, 50)
+    vals = a.values.copy()
+    vals[[7, 1000, 5555]] *= 1.5
+    b = la.CrsMatrix(vals, a.column_index, a.row_head_indexes)
+    x = np.random.default_rng(2).standard_normal(b.dimension)
+    with la.Engine(b, 3, spmv="dict") as e:
+        assert int(e.spmv_name[4:]) == 9 + 3
+        assert np.all(np.abs(e.spmv(x) - oracle.matvec_crs(b.row_head_indexes, b.column_index, b.values, x))
+                      <= spmv_tolerance(b, x))
+    with pytest.raises(la.LanczosHipError, match="dictionary SpMV needs rows"):
+        la.Engine(irregular_matrix(3000, 1), 3, spmv="dict")          # rows up to 60 entries
+    r = la.synth_random_symmetric(100000, 3, 5)                        # short rows, 100000 distinct patterns
+    with pytest.raises(la.LanczosHipError, match="dictionary SpMV needs rows"):
+        la.Engine(r, 3, spmv="dict")
 
 
 def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
@@ -170,7 +208,7 @@ def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
     assert np.all(np.abs(yg - oracle.matvec_crs(big.row_head_indexes, big.column_index, big.values, xg))
                   <= spmv_tolerance(big, xg))
     with la.Engine(la.synth_laplacian(3, 64), 3) as e:
-        assert e.spmv_name.startswith("rows")
+        assert e.spmv_name == "dict27"
 
 
 def test_device_coo_to_crs_is_bit_exact(gpu, golden_dir):
