@@ -68,7 +68,8 @@ k_dict_assign(int64_t n, const uint64_t *__restrict__ hash, const uint64_t *__re
             else hi = mid;
         }
         pattern[r] = (uint16_t)lo;
-        atomicMin(&rep[lo], (int)r);
+        // rep only ever decreases: a plain look first keeps 16 M atomics off a handful of addresses
+        if (__builtin_nontemporal_load(&rep[lo]) > (int)r) atomicMin(&rep[lo], (int)r);
     }
 }
 
