@@ -48,7 +48,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="lap256", choices=sorted(WORKLOADS))
     ap.add_argument("--reorth", default="full", choices=["full", "full2", "mgs", "cuda_compat", "none", "selective"])
-    ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows", "panel", "dict"])
+    ap.add_argument("--spmv", default="auto", choices=["auto", "vector", "stream", "pipe", "pipe_nt", "rows", "panel", "dict", "merge"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-block", action="store_true", help="skip the block-variant section")
     ap.add_argument("--rand-rows", type=int, default=10_000_000,

@@ -125,6 +125,8 @@ enum {
                                     number per row replaces the row's entries; for matrices whose rows
                                     repeat (stencils on grids), at most 65535 patterns of at most 32
                                     entries, found and verified entry by entry on the device */
+    LANCZOS_HIP_SPMV_MERGE = 8,  /* equal shares of entries per wavefront, rows found by binary search: for
+                                    wildly uneven row lengths (power-law graphs) */
     LANCZOS_HIP_SPMV_ROWS = 5    /* pipe form whose gathers run row-wise (coalesced for stencil-like
                                     matrices); needs every 64-row group to hold <= 512 entries */
 };

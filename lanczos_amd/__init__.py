@@ -52,7 +52,7 @@ class Options(C.Structure):
 
 
 REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "mgs": 3, "full2": 4, "selective": 5}
-SPMV = {"auto": 0, "vector": 1, "stream": 2, "pipe": 3, "pipe_nt": 4, "rows": 5, "panel": 6, "dict": 7}
+SPMV = {"auto": 0, "vector": 1, "stream": 2, "pipe": 3, "pipe_nt": 4, "rows": 5, "panel": 6, "dict": 7, "merge": 8}
 KERNEL_CLASSES = ("spmv", "recur", "scale", "dots", "update", "small")
 
 # ---- prototypes -----------------------------------------------------------

@@ -49,8 +49,8 @@ struct BlockEngine {
     double *d_small = nullptr;  // G, Rinv, R1, R2: 4 x 256
     double *d_TA = nullptr, *d_TB = nullptr;
     int *d_status = nullptr;
-    int *d_long_rows = nullptr;  // rows with more than kLongRow entries
-    int n_long = 0;
+    int *d_med_rows = nullptr, *d_long_rows = nullptr;  // rows over kMedRow / over kLongRow entries
+    int n_med = 0, n_long = 0;
     bool profile = false;
     double prof_ms[LANCZOS_HIP_BK_COUNT] = {0};
     double prof_bytes[LANCZOS_HIP_BK_COUNT] = {0};
@@ -75,6 +75,7 @@ struct BlockEngine {
         (void)hipFree(d_TB);
         (void)hipFree(d_status);
         (void)hipFree(d_long_rows);
+        (void)hipFree(d_med_rows);
         delete base;
     }
 
@@ -129,20 +130,28 @@ struct BlockEngine {
         HIP_TRY(hipMalloc(&d_TB, sizeof(double) * 256 * (size_t)max_steps));
         HIP_TRY(hipMalloc(&d_status, sizeof(int) * 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int) * 4, stream()));
-        // hub rows get a workgroup each; at most nnz / kLongRow rows can qualify
-        const int cap = (int)std::min<int64_t>(n, base->nnz / kLongRow + 1);
-        HIP_TRY(hipMalloc(&d_long_rows, sizeof(int) * (size_t)cap));
+        // rows too long for eight lanes get a wavefront or a workgroup each; at most nnz / threshold
+        // rows can qualify
+        const int med_cap = (int)std::min<int64_t>(n, base->nnz / kMedRow + 1);
+        const int lng_cap = (int)std::min<int64_t>(n, base->nnz / kLongRow + 1);
+        HIP_TRY(hipMalloc(&d_med_rows, sizeof(int) * (size_t)med_cap));
+        HIP_TRY(hipMalloc(&d_long_rows, sizeof(int) * (size_t)lng_cap));
         const int fb = (int)std::min<int64_t>(groups_spmm, (n + kThreads - 1) / kThreads);
         if (base->rp64)
             hipLaunchKernelGGL((k_find_long_rows<int64_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
-                               (const int64_t *)base->d_rp, d_long_rows, cap, d_status + 1);
+                               (const int64_t *)base->d_rp, d_med_rows, med_cap, d_long_rows, lng_cap, d_status + 1);
         else
             hipLaunchKernelGGL((k_find_long_rows<int32_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
-                               (const int32_t *)base->d_rp, d_long_rows, cap, d_status + 1);
+                               (const int32_t *)base->d_rp, d_med_rows, med_cap, d_long_rows, lng_cap, d_status + 1);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(&n_long, d_status + 1, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        int counts[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(counts, d_status + 1, sizeof(counts), hipMemcpyDeviceToHost, stream()));
         HIP_TRY(hipStreamSynchronize(stream()));
-        if (n_long > cap) return lz::fail("lanczos_hip_block_create: long-row list overflow (%d > %d)", n_long, cap);
+        n_med = counts[0];
+        n_long = counts[1];
+        if (n_med > med_cap || n_long > lng_cap)
+            return lz::fail("lanczos_hip_block_create: long-row list overflow (%d > %d or %d > %d)", n_med, med_cap,
+                            n_long, lng_cap);
         return 0;
     }
 
@@ -158,6 +167,17 @@ struct BlockEngine {
         else
             hipLaunchKernelGGL((k_spmm16<int32_t>), dim3(groups_spmm), dim3(kThreads), 0, stream(), n, n_pad,
                                (const int32_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+        if (n_med > 0) {
+            const int mb = (n_med + 3) / 4;
+            if (base->rp64)
+                hipLaunchKernelGGL((k_spmm16_medium<int64_t>), dim3(mb), dim3(kThreads), 0, stream(),
+                                   (const int *)d_med_rows, n_med, (const int64_t *)base->d_rp, base->d_col,
+                                   base->d_val, X, Y);
+            else
+                hipLaunchKernelGGL((k_spmm16_medium<int32_t>), dim3(mb), dim3(kThreads), 0, stream(),
+                                   (const int *)d_med_rows, n_med, (const int32_t *)base->d_rp, base->d_col,
+                                   base->d_val, X, Y);
+        }
         if (n_long > 0) {
             if (base->rp64)
                 hipLaunchKernelGGL((k_spmm16_long<int64_t>), dim3(n_long), dim3(kThreads), 0, stream(),

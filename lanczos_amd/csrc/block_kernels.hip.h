@@ -41,7 +41,8 @@ __device__ __forceinline__ double ld_nt(const double *p) { return __builtin_nont
 // ---------------------------------------------------------------------------
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-constexpr int kLongRow = 512;  // rows with more entries go to k_spmm16_long, one workgroup each
+constexpr int kMedRow = 64;     // rows with more entries leave the main kernel: one wavefront each (k_spmm16_medium)
+constexpr int kLongRow = 4096;  // ... and above this one workgroup each (k_spmm16_long)
 
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
@@ -67,7 +68,7 @@ k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__r
         if (qq < q_hi && r < n) {
             e0 = (int64_t)rp[r];
             const int64_t full = (int64_t)rp[r + 1] - e0;
-            len = full > kLongRow ? -1 : (int)full;  // -1: a long row, left to k_spmm16_long
+            len = full > kMedRow ? -1 : (int)full;  // -1: left to k_spmm16_medium / k_spmm16_long
             if (c < len) {
                 mycol = __builtin_nontemporal_load(col + e0 + c);
                 myval = __builtin_nontemporal_load(val + e0 + c);
@@ -110,16 +111,60 @@ k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__r
     }
 }
 
-// rows[0 .. count) = the rows with more than kLongRow entries (any order), count[0] their number
+// med[0 .. count[0]) = the rows with kMedRow < entries <= kLongRow, lng[0 .. count[1]) those with more
+// (any order)
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
-k_find_long_rows(int64_t n, const RP *__restrict__ rp, int *__restrict__ rows, int capacity, int *__restrict__ count) {
+k_find_long_rows(int64_t n, const RP *__restrict__ rp, int *__restrict__ med, int med_cap, int *__restrict__ lng,
+                 int lng_cap, int *__restrict__ count) {
     const int64_t stride = (int64_t)gridDim.x * kThreads;
-    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < n; r += stride)
-        if ((int64_t)rp[r + 1] - (int64_t)rp[r] > kLongRow) {
+    for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < n; r += stride) {
+        const int64_t len = (int64_t)rp[r + 1] - (int64_t)rp[r];
+        if (len > kLongRow) {
+            const int at = atomicAdd(count + 1, 1);
+            if (at < lng_cap) lng[at] = (int)r;
+        } else if (len > kMedRow) {
             const int at = atomicAdd(count, 1);
-            if (at < capacity) rows[at] = (int)r;
+            if (at < med_cap) med[at] = (int)r;
         }
+    }
+}
+
+// One wavefront per medium row: the 64 lanes load 64 (col, val) pairs at a time, each group of
+// eight lanes takes every eighth of them, and the eight partial rows are added by butterfly
+// exchange, the same way on every run.
+template <typename RP>
+__global__ void __launch_bounds__(kThreads)
+k_spmm16_medium(const int *__restrict__ rows, int count, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+                const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y) {
+    const int lane = threadIdx.x & 63, c = lane & 7, g = lane >> 3;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= count) return;
+    const int r = rows[i];
+    const int64_t e0 = (int64_t)rp[r], e1 = (int64_t)rp[r + 1];
+    d2v acc = d2v{0.0, 0.0};
+    for (int64_t p = e0; p < e1; p += 64) {  // uniform over the wavefront
+        int mycol = 0;
+        double myval = 0.0;
+        if (p + lane < e1) {
+            mycol = col[p + lane];
+            myval = val[p + lane];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int cj = __shfl(mycol, 8 * j + g);
+            const double vj = __shfl(myval, 8 * j + g);
+            const d2v x = *reinterpret_cast<const d2v *>(X + (int64_t)cj * kW + 2 * c);
+            acc.x += vj * x.x;
+            acc.y += vj * x.y;
+        }
+    }
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        acc.x += __shfl_xor(acc.x, off);
+        acc.y += __shfl_xor(acc.y, off);
+    }
+    if (g == 0) *reinterpret_cast<d2v *>(Y + (int64_t)r * kW + 2 * c) = acc;
 }
 
 // One workgroup per long row (a hub of a power-law graph): its 32 groups of eight lanes take the

@@ -165,7 +165,7 @@ int Engine::create_from_coo(Engine **out, const Mat_Coo *coo, int swap, int max_
     if (opt_in) memcpy(&opt, opt_in, std::min(sizeof(opt), opt_in->struct_size));
     if (opt.reorth < 0 || opt.reorth > LANCZOS_HIP_REORTH_SELECTIVE)
         return fail("lanczos_hip_create_from_coo: bad reorth mode %d", opt.reorth);
-    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_DICT)
+    if (opt.spmv_kernel < 0 || opt.spmv_kernel > LANCZOS_HIP_SPMV_MERGE)
         return fail("lanczos_hip_create_from_coo: bad spmv_kernel %d", opt.spmv_kernel);
     if (!coo || (coo->length > 0 && !coo->data)) return fail("convert_from_coo: mat_coo is NULL");
     if (coo->dimension == 0) return fail("convert_from_coo: dimension is 0");

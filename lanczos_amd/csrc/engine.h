@@ -61,6 +61,10 @@ struct Engine {
     int group = 8;   // lanes per row of the vector kernel
     int log2r = 6;   // log2(rows per wavefront group) of the pipe kernel
     char spmv_name[32] = "";
+    int *d_tile_rows = nullptr;        // merge SpMV: first and last row of every tile of 512 entries
+    int *d_carry_row = nullptr;        // merge SpMV: rows shared between tiles, two slots per tile
+    double *d_carry_val = nullptr;
+    long long *d_xcd_split = nullptr;  // [9] chunk ranges of the pipe kernel, equal entries per XCD
     // tiled form of the matrix (LANCZOS_HIP_SPMV_PANEL): entries grouped by (row block, column panel)
     uint32_t *d_packed = nullptr;    // row in block << 20 | column in panel
     double *d_pval = nullptr;

@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <vector>
 
+#include "balance.hip.h"
 #include "kernels.hip.h"
 
 namespace lz {
@@ -99,7 +100,7 @@ static int read_options(lanczos_hip_options *opt, const lanczos_hip_options *opt
     if (opt_in) memcpy(opt, opt_in, std::min(sizeof(*opt), opt_in->struct_size));
     if (opt->reorth < 0 || opt->reorth > LANCZOS_HIP_REORTH_SELECTIVE)
         return fail("lanczos_hip_create: bad reorth mode %d", opt->reorth);
-    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_DICT)
+    if (opt->spmv_kernel < 0 || opt->spmv_kernel > LANCZOS_HIP_SPMV_MERGE)
         return fail("lanczos_hip_create: bad spmv_kernel %d", opt->spmv_kernel);
     return 0;
 }
@@ -270,7 +271,40 @@ int Engine::choose_spmv(int requested) {
     log2r = 6;
     while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
     if (log2r == 1) log2r = 0;
-    if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
+    // wildly uneven rows (the fullest 64-row group holds 16 times the average): shares of entries
+    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE && requested == LANCZOS_HIP_SPMV_AUTO &&
+        (double)max_span > 16.0 * 64.0 * std::max(mean, 1.0))
+        spmv_kind = LANCZOS_HIP_SPMV_MERGE;
+    if (spmv_kind == LANCZOS_HIP_SPMV_MERGE) {
+        const int64_t tiles = (nnz + kTile - 1) / kTile;
+        HIP_TRY(hipMalloc(&d_carry_row, sizeof(int) * 2 * std::max<int64_t>(tiles, 1)));
+        HIP_TRY(hipMalloc(&d_carry_val, sizeof(double) * 2 * std::max<int64_t>(tiles, 1)));
+        HIP_TRY(hipMalloc(&d_tile_rows, sizeof(int) * 2 * std::max<int64_t>(tiles, 1)));
+        const int tb = (int)std::min<int64_t>(max_blocks, (2 * tiles + kBlock - 1) / kBlock);
+        if (rp64)
+            hipLaunchKernelGGL((k_merge_tile_rows<int64_t>), dim3(tb), dim3(kBlock), 0, stream, n, nnz,
+                               (const int64_t *)d_rp, d_tile_rows);
+        else
+            hipLaunchKernelGGL((k_merge_tile_rows<int32_t>), dim3(tb), dim3(kBlock), 0, stream, n, nnz,
+                               (const int32_t *)d_rp, d_tile_rows);
+        HIP_TRY(hipGetLastError());
+    }
+    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {
+        const int64_t groups = (n + (1 << log2r) - 1) >> log2r;
+        const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+        if (!d_xcd_split) HIP_TRY(hipMalloc(&d_xcd_split, sizeof(long long) * 9));
+        if (rp64)
+            hipLaunchKernelGGL((k_balance_split<int64_t>), dim3(1), dim3(64), 0, stream, n, (const int64_t *)d_rp,
+                               (int64_t)kWavesPerBlock << log2r, chunks, d_xcd_split);
+        else
+            hipLaunchKernelGGL((k_balance_split<int32_t>), dim3(1), dim3(64), 0, stream, n, (const int32_t *)d_rp,
+                               (int64_t)kWavesPerBlock << log2r, chunks, d_xcd_split);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    if (spmv_kind == LANCZOS_HIP_SPMV_MERGE)
+        snprintf(spmv_name, sizeof(spmv_name), "merge%s", rp64 ? "_rp64" : "");
+    else if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
         snprintf(spmv_name, sizeof(spmv_name), "dict%d", dict_patterns);
     else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
         snprintf(spmv_name, sizeof(spmv_name), "panel%d", panel_bits);
@@ -331,6 +365,10 @@ Engine::~Engine() {
     for (auto ev : event_pool) (void)hipEventDestroy(ev);
     free_panels();
     free_dict();
+    (void)hipFree(d_xcd_split);
+    (void)hipFree(d_tile_rows);
+    (void)hipFree(d_carry_row);
+    (void)hipFree(d_carry_val);
     (void)hipFree(d_val);
     (void)hipFree(d_col);
     (void)hipFree(d_rp);
@@ -372,6 +410,18 @@ double Engine::spmv_bytes() const {
 template <typename RP>
 static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double *y, int *nparts) {
     const RP *rp = (const RP *)e->d_rp;
+    if (e->spmv_kind == LANCZOS_HIP_SPMV_MERGE) {
+        const int64_t tiles = (e->nnz + kTile - 1) / kTile;
+        const int fix = 64;
+        int blocks = (int)std::min<int64_t>(e->max_blocks - fix, round_up((tiles + kWavesPerBlock - 1) / kWavesPerBlock, 8));
+        *nparts = blocks + fix;
+        (void)hipMemsetAsync(y, 0, sizeof(double) * e->n, e->stream);
+        hipLaunchKernelGGL((k_spmv_merge<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, e->nnz, rp, e->d_col,
+                           e->d_val, x, xdot, y, e->d_partials, (const int *)e->d_tile_rows, e->d_carry_row, e->d_carry_val);
+        hipLaunchKernelGGL(k_merge_fixup, dim3(fix), dim3(kBlock), 0, e->stream, 2 * tiles, (const int *)e->d_carry_row,
+                           (const double *)e->d_carry_val, xdot, y, e->d_partials + blocks);
+        return;
+    }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_ROWS) {
         const int64_t groups = (e->n + 63) / 64;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -392,10 +442,10 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double
     case LR:                                                                                                   \
         if (nt)                                                                                                \
             hipLaunchKernelGGL((k_spmv_pipe<RP, LR, true>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,   \
-                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials);                             \
+                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials, e->d_xcd_split);             \
         else                                                                                                   \
             hipLaunchKernelGGL((k_spmv_pipe<RP, LR, false>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,  \
-                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials);                             \
+                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials, e->d_xcd_split);             \
         break;
         switch (lr) {
             LZ_PIPE_CASE(6)

@@ -257,21 +257,18 @@ __global__ void __launch_bounds__(kBlock)
 k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
             const double *__restrict__ val, const double *__restrict__ x,
             const double *__restrict__ xdot, double *__restrict__ y,
-            double *__restrict__ partials) {
+            double *__restrict__ partials, const long long *__restrict__ xcd_split) {
     __shared__ double prod[kWavesPerBlock][kTile];
     __shared__ double red[kWavesPerBlock];
     constexpr int R = 1 << LOG2R;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t groups = (n + R - 1) >> LOG2R;
-    const int64_t total = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
-    const int64_t per_xcd = (total + 7) >> 3;
     const int64_t xcd = blockIdx.x & 7;
     const int64_t slot = blockIdx.x >> 3;
     const int64_t slots = gridDim.x >> 3;
-    int64_t c_end = (xcd + 1) * per_xcd;
-    if (c_end > total) c_end = total;
-    const int64_t c0 = xcd * per_xcd + slot;
+    // this XCD's range of chunks (4 groups each), cut so that the ranges hold equal numbers of entries
+    const int64_t c_end = xcd_split[xcd + 1];
+    const int64_t c0 = xcd_split[xcd] + slot;
     const int64_t count = c0 < c_end ? (c_end - c0 + slots - 1) / slots : 0;
     double *myprod = prod[wave];
     double acc = 0.0;
@@ -374,6 +371,134 @@ k_spmv_pipe(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
             step(i + 1, cB, vB, cA, vA, loB, hiB, loA, hiA);
         }
         if (i < count) step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// ---------------------------------------------------------------------------
+// SpMV, "merge" form: equal shares of ENTRIES, not of rows
+// ---------------------------------------------------------------------------
+//
+// For matrices whose row lengths are wildly uneven (power-law graphs: most rows
+// hold a handful of entries, some hold tens of thousands) any fixed number of
+// rows per wavefront leaves most lanes idle.  Here a wavefront takes tiles of
+// kTile consecutive entries, finds the rows they belong to by binary search in
+// the row offsets, multiplies with fully used coalesced loads, and sums each
+// row's slice of the tile (slice_sum: rows of 64 or more entries are summed by
+// the whole wavefront).  A row that lies inside one tile is written at once; the
+// at most two rows a tile shares with its neighbours leave their partial sums in
+// carry[2 * tile + {0, 1}], which k_merge_fixup adds up in tile order: no atomics,
+// the same sums on every run.  y must be zero on entry (empty rows, shared rows).
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_merge(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+             const double *__restrict__ val, const double *__restrict__ x, const double *__restrict__ xdot,
+             double *__restrict__ y, double *__restrict__ partials, const int *__restrict__ tile_rows,
+             int *__restrict__ carry_row, double *__restrict__ carry_val) {
+    __shared__ double prod[kWavesPerBlock][kTile];
+    __shared__ double red[kWavesPerBlock];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t tiles = (nnz + kTile - 1) / kTile;
+    const int64_t per_xcd = (tiles + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    int64_t t_end = (xcd + 1) * per_xcd;
+    if (t_end > tiles) t_end = tiles;
+    double *myprod = prod[wave];
+    double acc = 0.0;
+    for (int64_t t = xcd * per_xcd + slot * kWavesPerBlock + wave; t < t_end; t += slots * kWavesPerBlock) {
+        const int64_t e0 = t * kTile, e1 = (e0 + kTile < nnz) ? e0 + kTile : nnz;
+        const int64_t row_lo = tile_rows[2 * t], row_hi = tile_rows[2 * t + 1];  // rows of its first / last entry
+#pragma unroll
+        for (int u = 0; u < kTileU; ++u) {
+            const int64_t j = e0 + u * 64 + lane;
+            myprod[u * 64 + lane] = j < e1 ? val[j] * x[col[j]] : 0.0;
+        }
+        __builtin_amdgcn_wave_barrier();
+        int c_row0 = -1, c_row1 = -1;  // wave-uniform: the rows shared with the previous / next tile
+        double c_val0 = 0.0, c_val1 = 0.0;
+        for (int64_t base = row_lo; base <= row_hi; base += 64) {
+            const int64_t r = base + lane;
+            const bool valid = r <= row_hi;
+            const int64_t a = valid ? (int64_t)rp[r] : e1, b = valid ? (int64_t)rp[r + 1] : e1;
+            const int64_t lo = a > e0 ? a : e0, hi = b < e1 ? b : e1;
+            const bool some = valid && hi > lo;
+            const double sum = slice_sum(myprod, some ? (int)(lo - e0) : 0, some ? (int)(hi - e0) : 0, lane);
+            const bool whole = some && a >= e0 && b <= e1;
+            if (whole) {
+                y[r] = sum;
+                acc += xdot[r] * sum;
+            }
+            const bool head = some && a < e0;               // continues a row of the previous tile
+            const bool tail = some && !head && b > e1;      // continued by the next tile
+            const unsigned long long mh = __ballot(head), mt = __ballot(tail);
+            if (mh) {
+                const int src = __ffsll((long long)mh) - 1;
+                c_row0 = (int)__shfl((int)r, src);
+                c_val0 = __shfl(sum, src);
+            }
+            if (mt) {
+                const int src = __ffsll((long long)mt) - 1;
+                c_row1 = (int)__shfl((int)r, src);
+                c_val1 = __shfl(sum, src);
+            }
+        }
+        if (lane == 0) {
+            carry_row[2 * t] = c_row0;
+            carry_val[2 * t] = c_val0;
+            carry_row[2 * t + 1] = c_row1;
+            carry_val[2 * t + 1] = c_val1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
+// tile_rows[2 t], [2 t + 1] = the rows holding the first and the last entry of tile t (the row
+// holding entry e is the first r with rp[r + 1] > e); computed once per matrix
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_merge_tile_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, int *__restrict__ tile_rows) {
+    const int64_t tiles = (nnz + kTile - 1) / kTile;
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < 2 * tiles; i += step) {
+        const int64_t t = i >> 1;
+        const int64_t last = (t * kTile + kTile < nnz ? t * kTile + kTile : nnz) - 1;
+        const int64_t e = (i & 1) ? last : t * kTile;
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)rp[mid + 1] > e) hi = mid;
+            else lo = mid + 1;
+        }
+        tile_rows[i] = (int)lo;
+    }
+}
+
+// The rows shared between tiles: the first carry of every run of equal rows adds the run up, in
+// tile order, and writes the row.  partials[b] = this workgroup's part of xdot . y over those rows.
+__global__ void __launch_bounds__(kBlock)
+k_merge_fixup(int64_t count, const int *__restrict__ carry_row, const double *__restrict__ carry_val,
+              const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    const int64_t step = (int64_t)gridDim.x * kBlock;
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < count; i += step) {
+        const int row = carry_row[i];
+        if (row < 0) continue;
+        int64_t j = i - 1;
+        while (j >= 0 && carry_row[j] < 0) --j;
+        if (j >= 0 && carry_row[j] == row) continue;  // not the first of its run
+        double s = 0.0;
+        for (int64_t k = i; k < count; ++k) {
+            const int rk = carry_row[k];
+            if (rk < 0) continue;
+            if (rk != row) break;
+            s += carry_val[k];
+        }
+        y[row] = s;
+        acc += xdot[row] * s;
     }
     const double total_acc = block_sum(acc, red);
     if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
