@@ -119,6 +119,7 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     if (bad) return lz::fail("lanczos_hip_checkpoint_load: read from %s failed", path);
     e->k = h.k;
     e->lazy_flushed_k = h.lazy_flushed_k;
+    e->spec_spmv_k = -1;
     e->alpha_count = h.alpha_count;
     e->norm_count = h.norm_count;
     e->reorth_steps = h.reorth_steps;

@@ -40,6 +40,7 @@ struct Engine {
     int alpha_count = 0, norm_count = 0;
     bool lazy = false;               // deferred normalisation (three-vector mode on one GPU)
     int lazy_flushed_k = 0;
+    int spec_spmv_k = -1;            // iteration whose product was already launched ahead (selective mode)
     double *d_hpart = nullptr;
     int hstride = 0;
     double *d_red = nullptr;   // [max_iter] reduction results (single-GPU runs)
@@ -131,6 +132,7 @@ struct Engine {
     int combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld);
     int restart(int p, const double *coef_host, double last_coupling);
     int selective_tail();
+    int selective_lazy_tail();
     int run(int steps, double *alpha_out, double *beta_out);
     int spmv_host(const double *x_host, double *y_host);
     int enable_host_history();

@@ -332,7 +332,7 @@ int Engine::alloc_state() {
     HIP_TRY(hipMalloc(&d_partials, sizeof(double) * max_blocks));
     HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
     HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
-    lazy = (reorth == LANCZOS_HIP_REORTH_NONE) && x_ext == nullptr;
+    lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && x_ext == nullptr;
     hstride = max_blocks;
     const int hl = std::min(max_iter, kMaxDotsSegment);
     HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)hstride * (size_t)hl));
@@ -571,6 +571,7 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
     HIP_TRY(hipStreamSynchronize(stream));  // v0 may be pageable host memory
     k = 0;
     lazy_flushed_k = 0;
+    spec_spmv_k = -1;
     norm_count = 0;
     reorth_steps = 0;
     if (omega) lanczos_hip_omega_reset(omega);
@@ -686,7 +687,9 @@ int Engine::flush_lazy() {
 // into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
     if (int rc = check_can_step()) return rc;
-    if (int rc = launch_spmv(vec(k), vec(k), vec(k + 1), &alpha_count)) return rc;
+    if (spec_spmv_k != k)  // else: launched ahead by the previous iteration, on the vector that stood
+        if (int rc = launch_spmv(vec(k), vec(k), vec(k + 1), &alpha_count)) return rc;
+    spec_spmv_k = -1;
     if (lazy) {
         const int blocks = vec_blocks();
         {
@@ -698,6 +701,8 @@ int Engine::enqueue_iteration() {
         }
         norm_count = blocks;
         HIP_TRY(hipGetLastError());
+        if (reorth == LANCZOS_HIP_REORTH_SELECTIVE)
+            if (int rc = selective_lazy_tail()) return rc;
         k += 1;
         if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
         return 0;
@@ -746,6 +751,39 @@ int Engine::selective_tail() {
     if (int rc = launch_dots(0, k + 1, d_red)) return rc;
     if (int rc = launch_update(0, k + 1, d_red, &nparts)) return rc;
     return launch_scale(norm_parts(k), norm_count);
+}
+
+// The same decision on one GPU, where the basis is kept unnormalised (u_j = beta_{j-1} v_j, no
+// scaling pass).  While the host waits for ||w|| the next product is already running on the vector
+// as it stands; in the few steps that do reorthogonalise, that product is taken again.
+int Engine::selective_lazy_tail() {
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * norm_count);
+        hipLaunchKernelGGL(k_norm_host, dim3(1), dim3(kBlock), 0, stream, (const double *)norm_parts(k), norm_count,
+                           d_scal + 2, h_sel);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sel_event, stream));
+    if (k + 2 < nvec && k + 1 < hist_cap && k + 1 < max_iter - 1) {
+        if (int rc = launch_spmv(vec(k + 1), vec(k + 1), vec(k + 2), &alpha_count)) return rc;
+        spec_spmv_k = k + 1;
+    }
+    HIP_TRY(hipEventSynchronize(sel_event));
+    if (k > 0) lanczos_hip_omega_set_beta(omega, k - 1, h_hist[2 * (size_t)(k - 1) + 1]);
+    const int need = lanczos_hip_omega_step(omega, k, h_hist[2 * (size_t)k], h_sel[0], nullptr);
+    if (need < 0) return fail("lanczos_hip: orthogonality tracker out of step at iteration %d", k);
+    if (!need) return 0;
+    reorth_steps += 1;
+    int nparts = 0;
+    if (int rc = launch_dots(0, k + 1, d_red)) return rc;
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SMALL, 16.0 * (k + 1));
+        hipLaunchKernelGGL(k_lazy_coeff, dim3((k + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, d_red, k + 1,
+                           (const double *)d_beta);
+    }
+    if (int rc = launch_update(0, k + 1, d_red, &nparts)) return rc;
+    spec_spmv_k = -1;  // the vector changed under the product launched ahead
+    return 0;
 }
 
 // out_dev[i * out_ld + .] = sum_{l < m} coef_host[i * m + l] * v_l for i < count: eight at a time,
@@ -963,6 +1001,9 @@ int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *e
     if (residual_est)  // |beta_{steps-1} * last component|: the Lanczos bound on ||A y - theta y||
         for (int i = 0; i < m; ++i) residual_est[i] = fabs(b[(size_t)steps - 1] * S[(size_t)i * steps + steps - 1]);
     if (!vectors_host) return 0;
+    if (e->lazy)  // the resident basis is u_j = beta_{j-1} v_j
+        for (int i = 0; i < m; ++i)
+            for (int j = 1; j < steps; ++j) S[(size_t)i * steps + j] /= b[(size_t)j - 1];
     // y_i = sum_j S[i][j] v_j, eight at a time with one pass over the basis each
     double *d_y = nullptr;
     if (hipMalloc(&d_y, sizeof(double) * (size_t)e->ldv * (size_t)m) != hipSuccess)

@@ -813,6 +813,16 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
     }
 }
 
+// Coefficients against an unnormalised basis u_l = beta_{l-1} v_l (u_0 = v_0): the component of w
+// along u_l is (u_l . w) / ||u_l||^2.  h[l] holds u_l . w on entry.
+__global__ void __launch_bounds__(kBlock)
+k_lazy_coeff(double *__restrict__ h, int count, const double *__restrict__ beta_hist) {
+    const int l = blockIdx.x * kBlock + threadIdx.x;
+    if (l >= count || l == 0) return;
+    const double b = beta_hist[l - 1];
+    h[l] /= b * b;
+}
+
 // beta_hist[k] = sqrt(sum of partials): closes the last deferred iteration
 __global__ void __launch_bounds__(kBlock)
 k_lazy_flush(const double *__restrict__ norm_parts, int norm_count, double *__restrict__ beta_slot,
