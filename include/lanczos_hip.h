@@ -240,9 +240,12 @@ int lanczos_hip_profile(const lanczos_hip_engine *e, int kernel_class, double *m
                         int64_t *launches, double *bytes);
 void lanczos_hip_profile_reset(lanczos_hip_engine *e);
 
-/* Name of the SpMV kernel variant the engine selected ("rows64", "pipe16", "vector8", ...).
- * LANCZOS_HIP_SPMV_AUTO picks "rows" when every 64-row group fits one tile and, on a
- * sample of rows, most neighbouring rows hold neighbouring columns; "pipe" otherwise. */
+/* Name of the SpMV kernel variant the engine selected ("dict27", "rows64", "pipe16", "panel18",
+ * "merge", "vector8", ...).  LANCZOS_HIP_SPMV_AUTO decides from the matrix as it sits on the device:
+ * when, on a sample of rows, most neighbouring rows hold neighbouring columns, "dict" if the rows
+ * repeat as at most 65535 patterns, else "rows" if every 64-row group fits one tile; otherwise
+ * "panel" when the sampled rows reach across more than 16 MiB of the vector, "merge" when the
+ * fullest 64-row group holds 16 times the average, else "pipe". */
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
 
 /*

@@ -311,7 +311,8 @@ int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, co
     if (opt.x_ext) return lz::fail("lanczos_hip_block_create: row-partitioned matrices are not supported");
     const int want_profile = opt.profile;
     opt.struct_size = sizeof opt;
-    opt.reorth = LANCZOS_HIP_REORTH_NONE;  // the base engine only holds the matrix
+    opt.reorth = LANCZOS_HIP_REORTH_NONE;  // the base engine only holds the matrix:
+    opt.spmv_kernel = LANCZOS_HIP_SPMV_VECTOR;  // no format of its own to build
     opt.profile = 0;
     lz::Engine *base = nullptr;
     if (int rc = lz::Engine::create(&base, n, nnz, row_head_indexes, column_index, values, 2, &opt)) return rc;
