@@ -76,11 +76,17 @@ typedef struct crs {
  * EXIT_FAILURE on bad arguments or a HIP error (src/lanczos_cuda.c:316-327).
  *
  * Environment knobs (the argv contract of src/main.c:25-42 is unchanged):
- *   LANCZOS_HIP_REORTH  full | full2 | mgs | cuda_compat | none   (default full)
+ *   LANCZOS_HIP_REORTH  full | full2 | mgs | cuda_compat | none | selective   (default full)
  *   LANCZOS_HIP_SEED    start-vector seed (default 123456789, the constant of
  *                       src/lanczos_cuda.c:395)
  *   LANCZOS_HIP_DEVICE  HIP device ordinal (default: current device)
  *   LANCZOS_HIP_QUIET   1 suppresses the per-iteration stdout lines
+ *   LANCZOS_HIP_WINDOW  iterations enqueued ahead of the one the host is looking at (default 4)
+ *   LANCZOS_HIP_PROFILE 0 drops the per-kernel events behind the [TOTAL] lines (default 1)
+ *   LANCZOS_HIP_JSON    1 adds one JSON line with the same split to stderr
+ * and, read by every engine at creation:
+ *   LANCZOS_HIP_NO_DICT    1 keeps the CRS kernels on matrices whose rows repeat
+ *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 18)
  */
 int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
                     int nth_eig, int max_iter, double threshold);
@@ -116,6 +122,8 @@ enum {
     LANCZOS_HIP_SPMV_STREAM = 2, /* one wavefront per group of 64 rows, nnz streamed through LDS */
     LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups */
     LANCZOS_HIP_SPMV_PIPE_NT = 4, /* pipe form with non-temporal col/val loads */
+    LANCZOS_HIP_SPMV_ROWS = 5,   /* pipe form whose gathers run row-wise (coalesced for stencil-like
+                                    matrices); needs every 64-row group to hold <= 512 entries */
     LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
                                     caches (random sparsity): entries regrouped on the device by
                                     (block of 4096 rows, column panel of 2^18 columns); a workgroup keeps
@@ -125,10 +133,8 @@ enum {
                                     number per row replaces the row's entries; for matrices whose rows
                                     repeat (stencils on grids), at most 65535 patterns of at most 32
                                     entries, found and verified entry by entry on the device */
-    LANCZOS_HIP_SPMV_MERGE = 8,  /* equal shares of entries per wavefront, rows found by binary search: for
+    LANCZOS_HIP_SPMV_MERGE = 8   /* equal shares of entries per wavefront, rows found by binary search: for
                                     wildly uneven row lengths (power-law graphs) */
-    LANCZOS_HIP_SPMV_ROWS = 5    /* pipe form whose gathers run row-wise (coalesced for stencil-like
-                                    matrices); needs every 64-row group to hold <= 512 entries */
 };
 
 /* Kernel classes for lanczos_hip_profile(). */
