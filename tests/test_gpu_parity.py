@@ -96,6 +96,27 @@ def test_power_law_graph_laplacian(gpu, kind):
             assert e.spmv(x).tobytes() == y1.tobytes()
 
 
+@pytest.mark.parametrize("kind", SPMV_KINDS + ["rows", "panel", "dict", "auto"])
+def test_spmv_on_tiny_and_odd_sizes(gpu, kind):
+    """n = 1, 2, 3 and sizes around the wavefront / workgroup widths, sparse and dense-ish rows."""
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 3, 17, 63, 64, 65, 255, 256, 257, 1023, 4097):
+        if kind == "dict":
+            a = la.synth_laplacian(1, n)
+        else:
+            per = min(n, 5)
+            lens = rng.integers(0, per + 1, n)
+            head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            if head[-1] == 0:
+                lens[0], head = 1, np.concatenate([[0], np.cumsum(np.r_[1, lens[1:]])]).astype(np.int64)
+            cols = rng.integers(0, n, head[-1]).astype(np.int64)
+            a = la.CrsMatrix(rng.standard_normal(head[-1]), cols, head)
+        x = rng.standard_normal(n)
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        with la.Engine(a, 3, spmv=kind) as e:
+            assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(a, x)), (kind, n)
+
+
 def test_spmv_zero_matrix_and_auto_kernel(gpu, monkeypatch):
     n = 300
     a = la.CrsMatrix(np.zeros(0), np.zeros(0, np.int64), np.zeros(n + 1, np.int64))
