@@ -346,14 +346,21 @@ def single_gpu(args) -> dict:
 
 def main():
     args = parse_args()
+    # stdout carries the one JSON line and nothing else: whatever libraries print while the run
+    # lasts (RCCL's version banner goes to stdout) is sent to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from lanczos_amd.dist import bench_distributed
         out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS)
-        if out is not None:
-            print(json.dumps(out), flush=True)
-        return
-    print(json.dumps(single_gpu(args)), flush=True)
+    else:
+        out = single_gpu(args)
+    sys.stdout.flush()
+    if out is not None:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    os.close(json_fd)
 
 
 if __name__ == "__main__":
