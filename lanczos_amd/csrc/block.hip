@@ -209,19 +209,32 @@ struct BlockEngine {
         return 0;
     }
 
-    int update(int t0, int t1, double *W, const double *H) {
-        Scope ps(this, LANCZOS_HIP_BK_UPDATE, 8.0 * kW * (double)n * (t1 - t0 + 2));
-        hipLaunchKernelGGL(k_bupdate16, dim3(groups_update), dim3(kThreads), 0, stream(), (const double *)d_Q,
-                           blk_stride, t0, t1, W, n_pad, H);
+    // W -= sum_t Q_t H_t; with gram_out the kernel also leaves W^T W of the result there (no extra pass)
+    int update(int t0, int t1, double *W, const double *H, double *gram_out) {
+        {
+            Scope ps(this, LANCZOS_HIP_BK_UPDATE, 8.0 * kW * (double)n * (t1 - t0 + 2));
+            hipLaunchKernelGGL(k_bupdate16, dim3(groups_update), dim3(kThreads), 0, stream(), (const double *)d_Q,
+                               blk_stride, t0, t1, W, n_pad, H, gram_out ? d_hpart : (double *)nullptr);
+        }
+        if (gram_out) reduce_own_gram(gram_out);
         HIP_TRY(hipGetLastError());
         return 0;
     }
 
+    // G = sum over the update / scale workgroups' parts (one 16 x 16 block, fragment order in)
+    void reduce_own_gram(double *G) {
+        Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * groups_update);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(1), dim3(kThreads), 0, stream(), (const double *)d_hpart, groups_update,
+                           (int64_t)256, 256, G);
+    }
+
     // slot t <- orthonormal basis of its columns; Bout (optional) = the factor: old = new * Bout
-    int cholqr2(int t, double *Bout) {
+    // have_gram: d_small already holds W^T W of the block (left by the update that produced it)
+    int cholqr2(int t, double *Bout, bool have_gram) {
         double *G = d_small, *Rinv = d_small + 256, *R1 = d_small + 512, *R2 = d_small + 768;
         for (int pass = 0; pass < 2; ++pass) {
-            if (int rc = gram(t, t + 1, slot(t), G)) return rc;
+            if (pass == 0 && !have_gram)
+                if (int rc = gram(t, t + 1, slot(t), G)) return rc;
             {
                 Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * 3);
                 hipLaunchKernelGGL(k_chol16, dim3(1), dim3(kThreads), 0, stream(), (const double *)G, Rinv,
@@ -230,9 +243,11 @@ struct BlockEngine {
             }
             {
                 Scope ps(this, LANCZOS_HIP_BK_SCALE, 2.0 * 8.0 * kW * (double)n);
+                // the first scaling leaves the Gram matrix of its result for the second factorisation
                 hipLaunchKernelGGL(k_bscale16, dim3(groups_update), dim3(kThreads), 0, stream(), slot(t), n_pad,
-                                   (const double *)Rinv);
+                                   (const double *)Rinv, pass == 0 ? d_hpart : (double *)nullptr);
             }
+            if (pass == 0) reduce_own_gram(G);
         }
         HIP_TRY(hipGetLastError());
         return 0;
@@ -243,7 +258,7 @@ struct BlockEngine {
         HIP_TRY(hipMemsetAsync(d_Q, 0, sizeof(double) * (size_t)blk_stride * (size_t)(max_steps + 1), stream()));
         HIP_TRY(hipMemcpyAsync(slot(0), x0_host, sizeof(double) * (size_t)n * kW, hipMemcpyHostToDevice, stream()));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int), stream()));
-        if (int rc = cholqr2(0, nullptr)) return rc;
+        if (int rc = cholqr2(0, nullptr, false)) return rc;
         HIP_TRY(hipStreamSynchronize(stream()));
         harvest();
         steps = 0;
@@ -273,10 +288,10 @@ struct BlockEngine {
             hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, stream(), (const double *)(d_H + (j - ta) * 256),
                                d_TA + (size_t)j * 256);
         }
-        if (int rc = update(ta, j + 1, W, d_H)) return rc;
+        if (int rc = update(ta, j + 1, W, d_H, nullptr)) return rc;
         if (int rc = gram(0, j + 1, W, d_H)) return rc;
-        if (int rc = update(0, j + 1, W, d_H)) return rc;
-        if (int rc = cholqr2(j + 1, d_TB + (size_t)j * 256)) return rc;
+        if (int rc = update(0, j + 1, W, d_H, d_small)) return rc;
+        if (int rc = cholqr2(j + 1, d_TB + (size_t)j * 256, true)) return rc;
         steps += 1;
         return 0;
     }
@@ -418,7 +433,7 @@ int lanczos_hip_block_project(lanczos_hip_block *bh, int t0, int t1, int t_w, do
         return lz::fail("lanczos_hip_block_project: bad argument");
     HIP_TRY(hipSetDevice(b->base->device));
     if (int rc = b->gram(t0, t1, b->slot(t_w), b->d_H)) return rc;
-    if (int rc = b->update(t0, t1, b->slot(t_w), b->d_H)) return rc;
+    if (int rc = b->update(t0, t1, b->slot(t_w), b->d_H, nullptr)) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream()));
     b->harvest();
     if (h_out_host)
@@ -430,7 +445,7 @@ int lanczos_hip_block_orthonormalise(lanczos_hip_block *bh, int t, double *facto
     BlockEngine *b = B(bh);
     if (!b || t < 0 || t > b->max_steps) return lz::fail("lanczos_hip_block_orthonormalise: bad argument");
     HIP_TRY(hipSetDevice(b->base->device));
-    if (int rc = b->cholqr2(t, b->d_H)) return rc;
+    if (int rc = b->cholqr2(t, b->d_H, false)) return rc;
     HIP_TRY(hipStreamSynchronize(b->stream()));
     b->harvest();
     if (factor_out_host) HIP_TRY(hipMemcpy(factor_out_host, b->d_H, sizeof(double) * 256, hipMemcpyDeviceToHost));

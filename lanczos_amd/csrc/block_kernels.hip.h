@@ -277,10 +277,23 @@ k_gram_reduce(const double *__restrict__ hpart, int groups, int64_t hstride, int
 // ---------------------------------------------------------------------------
 constexpr int kLdsRow = 17;  // doubles per LDS tile row (16 + 1 against bank conflicts)
 
+// gpart[wg][e] = the workgroup's sum of its four wavefronts' accumulators, fragment order
+// (e = 64 r + lane), added in wavefront order.  `scratch` is >= 1024 doubles of LDS no longer in use.
+__device__ __forceinline__ void emit_gram_part(d4v g, double *scratch, double *__restrict__ gpart) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scratch[wave * 256 + r * 64 + lane] = g[r];
+    __syncthreads();
+    const int e = threadIdx.x;
+    gpart[(int64_t)blockIdx.x * 256 + e] = (scratch[e] + scratch[256 + e]) + (scratch[512 + e] + scratch[768 + e]);
+}
+
 __global__ void __launch_bounds__(kThreads)
 k_bupdate16(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, double *__restrict__ W,
-            int64_t n_pad, const double *__restrict__ H) {
+            int64_t n_pad, const double *__restrict__ H, double *__restrict__ gpart) {
     __shared__ double lds[4][kTileRows * kLdsRow];
+    d4v gacc = d4v{0.0, 0.0, 0.0, 0.0};  // this wavefront's part of W^T W of the result (gpart != NULL)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
     double *lt = lds[wave];
@@ -322,16 +335,22 @@ k_bupdate16(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, do
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W[off + (sub * 16 + 4 * r) * kW] = acc[sub][r];
+            for (int r = 0; r < 4; ++r) {
+                W[off + (sub * 16 + 4 * r) * kW] = acc[sub][r];
+                // a result register is rows 4r..4r+3 of the tile in exactly the operand layout
+                if (gpart) gacc = mfma16(acc[sub][r], acc[sub][r], gacc);
+            }
     }
+    if (gpart) emit_gram_part(gacc, reinterpret_cast<double *>(lds), gpart);
 }
 
 // W <- W M for a 16 x 16 matrix M (row-major): the triangular solve of CholQR
 // applied as a product with the inverse factor.  Same operand handling as
 // k_bupdate16 with the tile itself as the left operand.
 __global__ void __launch_bounds__(kThreads)
-k_bscale16(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M) {
+k_bscale16(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M, double *__restrict__ gpart) {
     __shared__ double lds[4][kTileRows * kLdsRow];
+    d4v gacc = d4v{0.0, 0.0, 0.0, 0.0};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int kk = lane >> 4, cc = lane & 15;
     double *lt = lds[wave];
@@ -354,9 +373,13 @@ k_bscale16(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M) 
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], mb[s], acc);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) W[off + (sub * 16 + 4 * r) * kW] = acc[r];
+            for (int r = 0; r < 4; ++r) {
+                W[off + (sub * 16 + 4 * r) * kW] = acc[r];
+                if (gpart) gacc = mfma16(acc[r], acc[r], gacc);
+            }
         }
     }
+    if (gpart) emit_gram_part(gacc, reinterpret_cast<double *>(lds), gpart);
 }
 
 // ---------------------------------------------------------------------------
