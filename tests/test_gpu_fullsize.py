@@ -1,6 +1,8 @@
 """Full-size checks on the benchmark configuration (3-D 7-point Laplacian 256^3,
 n = 16 777 216, nnz = 117 047 296) through size-independent properties, plus a
 short direct comparison with the CPU restatement."""
+import os
+
 import numpy as np
 import pytest
 
@@ -58,3 +60,31 @@ def test_first_steps_match_oracle_and_basis_stays_orthonormal(gpu, lap256):
         for i, u in enumerate(vecs):
             for j, w in enumerate(vecs):
                 assert abs(u @ w - (1.0 if i == j else 0.0)) < 1e-12
+
+
+def test_bench_line_keeps_its_contract(gpu):
+    """bench.py at N = 1 (shortened): exactly one JSON line on stdout with the agreed keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "2",
+                        "--cpu-steps", "6", "--rand-rows", "300000"], capture_output=True, text=True, timeout=600,
+                       cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 2 and d["dtype"] == "f64"
+    assert d["value"] > 0 and d["vs_baseline"] is None and "workload" in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and 0 < rf["frac"] < 1
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["gpu_same_sample_rel_err"]["alpha"] < 1e-10 and cb["gpu_same_sample_rel_err"]["beta"] < 1e-10
+    assert d["spmv_vector_step"]["iters_per_s"] > 0 and d["random_symmetric"]["iters_per_s"] > 0
+    assert d["selective_reorth"]["ritz_rel_diff_vs_full"] < 1e-10
