@@ -1,0 +1,68 @@
+"""Randomised differential run (scripts/gpu_fuzz.py) at a size that takes a few seconds: every SpMV
+kernel form, the 16-column SpMM and the device COO->CRS conversion on 200 matrices of varied shape."""
+import importlib.util
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_randomised_matrices_through_every_kernel_form(gpu, capsys):
+    spec = importlib.util.spec_from_file_location("gpu_fuzz", os.path.join(ROOT, "scripts", "gpu_fuzz.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.CASES, mod.SEED0 = 200, 5000
+    rc = mod.main()
+    out = capsys.readouterr().out
+    assert rc == 0, out[-4000:]
+    assert "200 cases" in out and " 0 failures" in out
+
+
+def _random_symmetric(rng, n):
+    """Symmetric CRS with unsorted rows: a random pattern plus its mirror plus a diagonal."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    per = int(rng.integers(1, 12))
+    rows = np.repeat(np.arange(n), per)
+    cols = rng.integers(0, n, rows.size)
+    vals = rng.standard_normal(rows.size)
+    m = sp.coo_matrix((vals, (rows, cols)), shape=(n, n))
+    m = (m + m.T + sp.diags(rng.standard_normal(n) * 3)).tocsr()
+    # shuffle the entries inside every row: the reference's container keeps file order, not column order
+    head = m.indptr.astype(np.int64)
+    key = np.repeat(np.arange(n), np.diff(head)) + rng.random(m.nnz)
+    order = np.argsort(key)
+    return m.data[order].astype(np.float64), m.indices[order].astype(np.int64), head
+
+
+@pytest.mark.parametrize("reorth,oracle_mode,tol", [("full", "full", 1e-11), ("mgs", "full", 1e-11),
+                                                    ("full2", "full", 1e-11), ("none", "none", 1e-9),
+                                                    ("cuda_compat", "cuda_compat", 1e-9),
+                                                    ("selective", "selective", 1e-9)])
+def test_random_symmetric_matrices_follow_the_oracle(gpu, reorth, oracle_mode, tol):
+    """alpha and beta of short runs on 25 random symmetric matrices of awkward sizes, every
+    reorthogonalisation mode against the CPU restatement of src/lanczos.c:104-191."""
+    import numpy as np
+
+    import lanczos_amd as la
+    import oracle
+    from matrices import rel_err
+
+    rng = np.random.default_rng(99)
+    sizes = [3, 5, 17, 63, 64, 65, 127, 129, 255, 257, 1023, 1025, 4095, 4097] + list(rng.integers(20, 30000, 11))
+    for n in sizes:
+        n = int(n)
+        vals, cols, head = _random_symmetric(rng, n)
+        a = la.CrsMatrix(vals, cols, head)
+        steps = min(n - 1, 12)
+        v0 = la.gaussian_fill(int(rng.integers(1, 1 << 30)), 0, n)
+        o = oracle.lanczos_crs(head, cols, vals, v0, min(2, steps), steps + 1, 0.0, oracle_mode)
+        with la.Engine(a, steps + 1, reorth=reorth) as e:
+            e.set_start(v0)
+            alpha, beta = e.run(steps)
+        scale = np.abs(o.alpha).max() + np.abs(o.beta).max()
+        assert np.max(np.abs(alpha - o.alpha[:steps])) < tol * scale, (reorth, n)
+        assert rel_err(beta, o.beta[:steps]) < tol, (reorth, n)
