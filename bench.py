@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--rand-rows", type=int, default=10_000_000,
                     help="rows of the random symmetric matrix (~21 entries per row) of the secondary section; "
                          "50000000 is the full-size configuration, 0 skips the section")
+    ap.add_argument("--big-grid", type=int, default=512,
+                    help="grid size N of the N^3 Laplacian of the strong-scaling section (SpMV + vector step, "
+                         "no reorthogonalisation: the basis of 300 vectors would not fit one GPU); 0 skips it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")
@@ -171,6 +174,44 @@ def random_symmetric_section(la, torch, rows: int, steps: int = 100) -> dict:
         "spmv_GBps": spmv_gbps,
         "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
         "generate_s": t_gen,
+    }
+
+
+def big_laplacian_section(la, torch, N: int, steps: int = 100) -> dict:
+    """SpMV + vector step on the N^3 7-point Laplacian (N = 512: n = 134 217 728, nnz = 937 951 232)
+    on one GPU: the single-GPU leg of the strong-scaling figure that `--gpus 2/4/8` report on the same
+    matrix, row-partitioned."""
+    t0 = time.perf_counter()
+    a = la.synth_laplacian(3, N)
+    t_gen = time.perf_counter() - t0
+    n, nnz = a.dimension, a.length
+    b = algorithmic_bytes(n, nnz)
+    t0 = time.perf_counter()
+    with la.Engine(a, 4, reorth="none", profile=True) as e:
+        t_up = time.perf_counter() - t0
+        e.set_start_seed(123456789)
+        e.run(5)
+        e.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = e.profile()
+        name = e.spmv_name
+    fmt_iter = prof["spmv"]["bytes"] / steps + 64.0 * n
+    return {
+        "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), SpMV + vector step, reorth=none",
+        "steps": steps,
+        "iters_per_s": steps / dt,
+        "ms_per_iter": dt / steps * 1e3,
+        "spmv_kernel": name,
+        "format_bytes_per_iter": fmt_iter,
+        "frac_of_hbm_peak": fmt_iter * steps / dt / 1e9 / HBM_PEAK_GBPS,
+        "crs_algorithmic_bytes_per_iter": b["iter"],
+        "crs_bytes_over_time_GBps": b["iter"] * steps / dt / 1e9,
+        "spmv_avg_ms": prof["spmv"]["ms"] / steps,
+        "setup_s": {"generate": t_gen, "upload": t_up},
     }
 
 
@@ -341,6 +382,9 @@ def single_gpu(args) -> dict:
         }
         del cb["alpha"], cb["beta"], cb["ritz"]
         out["cpu_baseline"] = cb
+    if args.big_grid > 0:
+        del a
+        out["strong_scaling_laplacian"] = big_laplacian_section(la, torch, args.big_grid)
     return out
 
 

@@ -523,6 +523,36 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                 "exchange": r3.plan.mode,
             }
         del r3
+    # ---- strong scaling on the large grid (SpMV + vector step): the matrix whose 300-vector basis
+    # does not fit one GPU; every rank generates its own slab
+    big = getattr(args, "big_grid", 0)
+    if big > 0:
+        nb = big ** 3
+        bb = partition_rows(nb, world)
+        slab = la.synth_laplacian_rows(3, big, bb[rank], bb[rank + 1])
+        nz = torch.tensor([float(slab.length)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nz)
+        nnz_b = int(nz.item())
+        r4 = build_gpu_rank(la, torch, comm, slab, bb, 4, reorth="none", spmv=args.spmv, profile=True)
+        v4 = la.gaussian_fill(123456789, bb[rank], bb[rank + 1] - bb[rank])
+        dt4 = _timed_dist_run(torch, dist, r4, v4, steps2, 5)
+        r4.history()
+        p4 = r4.engine.e.profile()
+        if rank == 0:
+            b = algorithmic_bytes(nb, nnz_b)
+            out["strong_scaling_laplacian"] = {
+                "workload": f"3-D 7-point Laplacian {big}^3 (n={nb}, nnz={nnz_b}), SpMV + vector step, reorth=none, "
+                            f"row-partitioned over {world} GPUs",
+                "steps": steps2,
+                "iters_per_s": steps2 / dt4,
+                "ms_per_iter": dt4 / steps2 * 1e3,
+                "spmv_kernel": r4.engine.e.spmv_name,
+                "crs_algorithmic_bytes_per_iter": b["iter"],
+                "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt4 / 1e9,
+                "spmv_avg_ms_rank0": p4["spmv"]["ms"] / steps2,
+                "exchange": r4.plan.mode,
+            }
+        del r4
     dist.barrier()
     dist.destroy_process_group()
     return out
