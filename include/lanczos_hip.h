@@ -313,10 +313,14 @@ const char *lanczos_hip_last_error(void);
  *   lanczos_hip_phase_spmv    w = A x_ext ; red[0] = local v_k . w
  *   lanczos_hip_phase_recur   alpha = red[0] ; w -= beta_prev v_{k-1} + alpha v_k ;
  *                             red[0..nl) = local V_l . w for the nl basis vectors
- *                             of the reorthogonalisation range (nl returned in *n_red;
- *                             with nl == 0: red[0] = local w.w and *n_red = 1,
- *                             *is_norm = 1)
- *   lanczos_hip_phase_update  w -= sum_l red[l] V_l ; red[0] = local w.w
+ *                             of the reorthogonalisation range and red[nl] = local w.w
+ *                             (*n_red = nl + 1 doubles to reduce, *is_norm = 0);
+ *                             with nl == 0: red[0] = local w.w, *n_red = 1, *is_norm = 1
+ *   lanczos_hip_phase_update  w -= sum_l red[l] V_l.  After phase_recur: red[0] = the
+ *                             GLOBAL norm^2 of the new w, red[nl] - sum_l red[l]^2 (the
+ *                             basis is orthonormal and the red[l] are rounding-level
+ *                             corrections, so nothing cancels): no further reduction.
+ *                             After phase_dots: red[0] = local w.w, to be reduced
  *   lanczos_hip_phase_scale   beta = sqrt(red[0]) ; v_{k+1} = w / beta ; k += 1
  *
  * lanczos_hip_local_vector returns the device address of basis vector k's

@@ -123,6 +123,7 @@ struct Engine {
     int flush_lazy();
     int launch_dots(int l0, int l1, double *red_out);
     int launch_update(int l0, int l1, const double *h, int *nparts);
+    bool red_has_norm = false;  // phase_recur left w.w behind the coefficients in the caller's buffer
     int phase_spmv(double *red);
     int phase_recur(double *red, int *n_red, int *is_norm);
     int phase_dots(double *red, int *n_red);

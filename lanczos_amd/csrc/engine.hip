@@ -643,11 +643,16 @@ int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
     if (l1 - l0 <= 0 || reorth == LANCZOS_HIP_REORTH_SELECTIVE) {  // selective: the caller decides about dots
         *n_red = 1;
         *is_norm = 1;
+        red_has_norm = false;
         return launch_finalize(norm_parts(k), norm_count, red);
     }
-    *n_red = l1 - l0;
+    // red[0..nl) = local V_l . w, red[nl] = local w.w: one reduction over ranks covers both, and
+    // phase_update derives the norm after the pass from them
+    *n_red = l1 - l0 + 1;
     *is_norm = 0;
-    return launch_dots(l0, l1, red);
+    red_has_norm = true;
+    if (int rc = launch_dots(l0, l1, red)) return rc;
+    return launch_finalize(norm_parts(k), norm_count, red + (l1 - l0));
 }
 
 int Engine::phase_dots(double *red, int *n_red) {
@@ -655,6 +660,7 @@ int Engine::phase_dots(double *red, int *n_red) {
     reorth_range(&l0, &l1);
     *n_red = l1 - l0;
     if (*n_red <= 0) return fail("lanczos_hip_phase_dots: empty range");
+    red_has_norm = false;
     return launch_dots(l0, l1, red);
 }
 
@@ -666,6 +672,14 @@ int Engine::phase_update(double *red) {
     // overwrites red[0] is ordered behind it on the stream
     int nparts = 0;
     if (int rc = launch_update(l0, l1, red, &nparts)) return rc;
+    if (red_has_norm) {  // red came from phase_recur, reduced over ranks: the global norm follows from it
+        red_has_norm = false;
+        ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (l1 - l0 + 1));
+        hipLaunchKernelGGL(k_pyth_norm, dim3(1), dim3(kBlock), 0, stream, (const double *)red, l1 - l0,
+                           (const double *)(red + (l1 - l0)), red);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     return launch_finalize(norm_parts(k), norm_count, red);
 }
 

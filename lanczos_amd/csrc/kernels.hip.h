@@ -847,6 +847,19 @@ k_norm_host(const double *__restrict__ parts, int count, double *__restrict__ ou
     }
 }
 
+// |w - V h|^2 for an orthonormal V and h = V^T w:  out[0] = ww[0] - sum_l h[l]^2 (clamped at 0).
+// h holds the few-ulp corrections of a reorthogonalisation pass, so nothing cancels; it saves a
+// row-partitioned run the separate reduction of the new norm.  out may alias h (h is read first).
+__global__ void __launch_bounds__(kBlock)
+k_pyth_norm(const double *__restrict__ h, int nl, const double *__restrict__ ww, double *__restrict__ out) {
+    __shared__ double red[kWavesPerBlock];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nl; i += kBlock) s += h[i] * h[i];
+    const double w2 = ww[0];
+    const double t = block_sum(s, red);
+    if (threadIdx.x == 0) out[0] = fmax(w2 - t, 0.0);
+}
+
 // v <- scale * v  (start-vector normalisation, src/lanczos.c:95-98)
 __global__ void __launch_bounds__(kBlock)
 k_scal_mul(double2 *__restrict__ v, int64_t n2, const double *__restrict__ norm2_p, double fixed) {

@@ -5,8 +5,9 @@ The reference has no multi-GPU code; the only thing to agree with is the
 single-GPU result.  The matrix is cut into contiguous row slabs.  Per iteration
 the ranks exchange the current Lanczos vector (halo exchange with the two
 neighbouring slabs when the matrix is banded, all-gather otherwise) and
-all-reduce three small buffers: alpha, the reorthogonalisation coefficients,
-and beta^2.  Everything else runs inside each rank's engine through the
+all-reduce two small buffers: alpha, then the reorthogonalisation coefficients
+together with w.w (the norm after the pass follows from them; without a
+reorthogonalisation range the second buffer is beta^2 alone).  Everything else runs inside each rank's engine through the
 phase-level C ABI (include/lanczos_hip.h).
 
 The host logic here (partition, column remap, exchange plan, iteration order)
@@ -210,7 +211,7 @@ class DistLanczos:
         self.plan, self.bounds, self.max_iter, self.reorth = plan, bounds, max_iter, reorth
         self.rank, self.world = comm.rank, comm.world
         self.x_ext = torch.zeros(plan.n_ext, dtype=torch.float64, device=device)
-        self.red = torch.zeros(max(max_iter, 8), dtype=torch.float64, device=device)
+        self.red = torch.zeros(max_iter + 8, dtype=torch.float64, device=device)
         self.engine = make_engine(plan, self.x_ext, max_iter)
         self.k = 0
         self.reorth_steps = 0
@@ -268,7 +269,7 @@ class DistLanczos:
         if self.reorth == "selective":
             self.ab[0:1].copy_(red[:1])
         n_red, is_norm = e.phase_recur(red)
-        self.comm.all_reduce_sum(red[:n_red])             # reorth coefficients, or beta^2
+        self.comm.all_reduce_sum(red[:n_red])             # reorth coefficients and w.w together, or beta^2
         if self.reorth == "selective":
             # the one host round trip per step: alpha_k and ||w||^2 for the decision rule
             self.ab[1:2].copy_(red[:1])
@@ -285,12 +286,12 @@ class DistLanczos:
                 norm2 = float(red[:1].cpu()[0])
             self.last_beta = float(np.sqrt(norm2))
         elif not is_norm:
-            e.phase_update(red)
+            e.phase_update(red)                           # red[0] = beta^2 over all ranks (from the reduced w.w)
             if self.reorth == "full2":
                 n2 = e.phase_dots(red)
                 self.comm.all_reduce_sum(red[:n2])
                 e.phase_update(red)
-            self.comm.all_reduce_sum(red[:1])             # beta^2
+                self.comm.all_reduce_sum(red[:1])         # beta^2 after the second pass
         e.phase_scale(red)
         self.k += 1
 
@@ -463,7 +464,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             "config": {
                 "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), {K} Lanczos steps from a fixed "
                             f"N(0,1) start vector, reorth={args.reorth}, row-partitioned over {world} GPUs "
-                            f"({runner.plan.mode} exchange + 3 all-reduces per step)",
+                            f"({runner.plan.mode} exchange + 2 all-reduces per step)",
                 "reorth": args.reorth,
                 "exchange": runner.plan.mode,
                 "parallelism": f"row-partition x{world}",

@@ -75,18 +75,26 @@ class NumpyPhaseEngine:
             red[0] = float(w @ w)
             return 1, True
         red[:nl] = torch.from_numpy(self.V[:nl] @ w)
-        return nl, False
+        red[nl] = float(w @ w)
+        self.red_has_norm = True
+        return nl + 1, False
 
     def phase_dots(self, red):
         nl = self._range()
         red[:nl] = torch.from_numpy(self.V[:nl] @ self.V[self.k + 1])
+        self.red_has_norm = False
         return nl
 
     def phase_update(self, red):
         nl = self._range()
         w = self.V[self.k + 1]
-        w -= red[:nl].numpy() @ self.V[:nl]
-        red[0] = float(w @ w)
+        h = red[:nl].numpy().copy()
+        w -= h @ self.V[:nl]
+        if getattr(self, "red_has_norm", False):
+            self.red_has_norm = False
+            red[0] = max(float(red[nl]) - float(h @ h), 0.0)   # global already: red was reduced over ranks
+        else:
+            red[0] = float(w @ w)
 
     def phase_scale(self, red):
         beta = float(np.sqrt(red[0]))
