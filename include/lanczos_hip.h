@@ -332,6 +332,21 @@ int lanczos_hip_phase_recur(lanczos_hip_engine *e, double *red, int *n_red, int 
 int lanczos_hip_phase_dots(lanczos_hip_engine *e, double *red, int *n_red);
 int lanczos_hip_phase_update(lanczos_hip_engine *e, double *red);
 int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red);
+/*
+ * LANCZOS_HIP_REORTH_NONE on a row-partitioned engine keeps the basis unnormalised,
+ * u_k = beta_{k-1} v_k (the recurrence of src/lanczos.c:150-180 with that substitution), so an
+ * iteration is two phases and ONE reduction of two doubles:
+ *   lanczos_hip_phase_spmv        w = A x_ext ; red[0] = local u_k . w ; red[1] = local |u_k|^2
+ *   lanczos_hip_phase_recur_lazy  alpha_k, beta_{k-1} from the reduced red[0..2) ;
+ *                                 u_{k+1} = w / beta_{k-1} - ... ; k += 1
+ * (lanczos_hip_phase_recur and lanczos_hip_phase_scale are refused there.)  The vector the host
+ * gathers into x_ext is u_k as it stands.  beta of the last iteration is still pending when the
+ * run stops: lanczos_hip_phase_lazy_norm leaves the local |u_k|^2 in red[0]; after the reduction
+ * lanczos_hip_phase_lazy_close records beta_{k-1} = sqrt(red[0]) for lanczos_hip_history.
+ */
+int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red);
+int lanczos_hip_phase_lazy_norm(lanczos_hip_engine *e, double *red);
+int lanczos_hip_phase_lazy_close(lanczos_hip_engine *e, double *red);
 double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k);
 /* Enqueue a device-to-device copy of basis vector k's local slab (n doubles) to dst. */
 int lanczos_hip_export_vector(lanczos_hip_engine *e, int k, double *dst_device);

@@ -110,7 +110,8 @@ _hip.lanczos_hip_tridiag_eigs.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
 _hip.lanczos_hip_tridiag_eigs.restype = C.c_int
 _hip.lanczos_hip_last_error.argtypes = []
 _hip.lanczos_hip_last_error.restype = C.c_char_p
-for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip_phase_scale"):
+for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip_phase_scale",
+              "lanczos_hip_phase_recur_lazy", "lanczos_hip_phase_lazy_norm", "lanczos_hip_phase_lazy_close"):
     getattr(_hip, _name).argtypes = [C.c_void_p, C.c_void_p]
     getattr(_hip, _name).restype = C.c_int
 _hip.lanczos_hip_phase_recur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -622,6 +623,15 @@ class Engine:
 
     def phase_scale(self, red: int):
         _check(_hip.lanczos_hip_phase_scale(self._h, red), "lanczos_hip_phase_scale")
+
+    def phase_recur_lazy(self, red: int):
+        _check(_hip.lanczos_hip_phase_recur_lazy(self._h, red), "lanczos_hip_phase_recur_lazy")
+
+    def phase_lazy_norm(self, red: int):
+        _check(_hip.lanczos_hip_phase_lazy_norm(self._h, red), "lanczos_hip_phase_lazy_norm")
+
+    def phase_lazy_close(self, red: int):
+        _check(_hip.lanczos_hip_phase_lazy_close(self._h, red), "lanczos_hip_phase_lazy_close")
 
     def local_vector_ptr(self, k: int) -> int:
         return _hip.lanczos_hip_local_vector(self._h, k)

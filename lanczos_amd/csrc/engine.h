@@ -40,6 +40,7 @@ struct Engine {
     int alpha_count = 0, norm_count = 0;
     bool lazy = false;               // deferred normalisation (three-vector mode on one GPU)
     int lazy_flushed_k = 0;
+    bool lazy_slab = false;          // deferred normalisation on a row slab (three-vector mode, phase calls)
     int spec_spmv_k = -1;            // iteration whose product was already launched ahead (selective mode)
     double *d_hpart = nullptr;
     int hstride = 0;
@@ -129,6 +130,9 @@ struct Engine {
     int phase_dots(double *red, int *n_red);
     int phase_update(double *red);
     int phase_scale(double *red);
+    int phase_recur_lazy(double *red);
+    int phase_lazy_norm(double *red);
+    int phase_lazy_close(double *red);
     int enqueue_iteration();
     int combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld);
     int restart(int p, const double *coef_host, double last_coupling);

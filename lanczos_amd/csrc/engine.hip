@@ -333,6 +333,7 @@ int Engine::alloc_state() {
     HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
     HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
     lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && x_ext == nullptr;
+    lazy_slab = reorth == LANCZOS_HIP_REORTH_NONE && x_ext != nullptr;
     hstride = max_blocks;
     const int hl = std::min(max_iter, kMaxDotsSegment);
     HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)hstride * (size_t)hl));
@@ -605,7 +606,43 @@ int Engine::phase_spmv(double *red) {
     if (int rc = check_can_step()) return rc;
     const double *x = x_ext ? x_ext : vec(k);
     if (int rc = launch_spmv(x, vec(k), vec(k + 1), &alpha_count)) return rc;
-    return launch_finalize(d_partials, alpha_count, red);
+    if (int rc = launch_finalize(d_partials, alpha_count, red)) return rc;
+    if (lazy_slab)  // the slab's part of |u_k|^2 rides along: one reduction over ranks per iteration
+        return launch_finalize(norm_parts(k - 1), k > 0 ? norm_count : 0, red + 1);
+    return 0;
+}
+
+// Recurrence with deferred normalisation on a row slab: red[0] = u_k . A u_k and red[1] = |u_k|^2,
+// both summed over ranks.  Leaves the slab's partials of |u_{k+1}|^2 for the next phase_spmv.
+int Engine::phase_recur_lazy(double *red) {
+    if (!lazy_slab) return fail("lanczos_hip_phase_recur_lazy: needs reorth=none on a row-partitioned engine");
+    const int blocks = vec_blocks();
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
+        hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
+                           (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, k,
+                           (const double *)red, 1, (const double *)(red + 1), 1, norm_parts(k), d_alpha, d_beta,
+                           h_hist);
+    }
+    norm_count = blocks;
+    HIP_TRY(hipGetLastError());
+    k += 1;
+    return 0;
+}
+
+// beta of the last deferred iteration: red[0] = this slab's |u_k|^2 ...
+int Engine::phase_lazy_norm(double *red) {
+    if (!lazy_slab || k == 0) return fail("lanczos_hip_phase_lazy_norm: nothing deferred");
+    return launch_finalize(norm_parts(k - 1), norm_count, red);
+}
+
+// ... and, summed over ranks, beta_{k-1} = sqrt(red[0]) into the history
+int Engine::phase_lazy_close(double *red) {
+    if (!lazy_slab || k == 0) return fail("lanczos_hip_phase_lazy_close: nothing deferred");
+    double *bhost = h_hist ? h_hist + 2 * (size_t)(k - 1) + 1 : nullptr;
+    hipLaunchKernelGGL(k_lazy_flush, dim3(1), dim3(kBlock), 0, stream, (const double *)red, 1, d_beta + (k - 1), bhost);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // w <- (w - beta v_{k-1}) - alpha v_k ; alpha = sum of alpha_parts[0..alpha_cnt)
@@ -636,6 +673,7 @@ int Engine::launch_scale(const double *parts, int cnt) {
 }
 
 int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
+    if (lazy_slab) return fail("lanczos_hip_phase_recur: reorth=none on a row slab runs phase_recur_lazy");
     // red[0] holds alpha (already reduced over ranks by the caller)
     if (int rc = launch_recur(red, 1)) return rc;
     int l0, l1;
@@ -1058,6 +1096,18 @@ int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red) {
 int lanczos_hip_phase_dots(lanczos_hip_engine *e, double *red, int *n_red) {
     if (!e || !red || !n_red) return lz::fail("lanczos_hip_phase_dots: NULL argument");
     return E(e)->phase_dots(red, n_red);
+}
+int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_recur_lazy: NULL argument");
+    return E(e)->phase_recur_lazy(red);
+}
+int lanczos_hip_phase_lazy_norm(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_lazy_norm: NULL argument");
+    return E(e)->phase_lazy_norm(red);
+}
+int lanczos_hip_phase_lazy_close(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_lazy_close: NULL argument");
+    return E(e)->phase_lazy_close(red);
 }
 int lanczos_hip_export_vector(lanczos_hip_engine *e, int k, double *dst_device) {
     if (!e || !dst_device || k < 0) return lz::fail("lanczos_hip_export_vector: bad argument");

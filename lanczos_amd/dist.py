@@ -6,8 +6,9 @@ single-GPU result.  The matrix is cut into contiguous row slabs.  Per iteration
 the ranks exchange the current Lanczos vector (halo exchange with the two
 neighbouring slabs when the matrix is banded, all-gather otherwise) and
 all-reduce two small buffers: alpha, then the reorthogonalisation coefficients
-together with w.w (the norm after the pass follows from them; without a
-reorthogonalisation range the second buffer is beta^2 alone).  Everything else runs inside each rank's engine through the
+together with w.w (the norm after the pass follows from them).  Without
+reorthogonalisation the basis stays unnormalised and ONE reduction of two
+doubles per iteration is enough.  Everything else runs inside each rank's engine through the
 phase-level C ABI (include/lanczos_hip.h).
 
 The host logic here (partition, column remap, exchange plan, iteration order)
@@ -215,6 +216,9 @@ class DistLanczos:
         self.engine = make_engine(plan, self.x_ext, max_iter)
         self.k = 0
         self.reorth_steps = 0
+        # no reorthogonalisation: unnormalised basis, one reduction of two doubles per iteration
+        self.lazy = reorth == "none" and hasattr(self.engine, "phase_recur_lazy")
+        self._closed_k = 0
         if reorth == "selective":
             # every rank holds the same alpha and beta, so every rank's tracker decides alike
             from . import OmegaTracker
@@ -239,6 +243,7 @@ class DistLanczos:
         self.engine.set_start_scaled(v0_local, 1.0 / np.sqrt(norm2))
         self.k = 0
         self.reorth_steps = 0
+        self._closed_k = 0
         if self.reorth == "selective":
             self.tracker.reset()
 
@@ -265,6 +270,11 @@ class DistLanczos:
         e, red = self.engine, self.red
         self.exchange()
         e.phase_spmv(red)
+        if self.lazy:
+            self.comm.all_reduce_sum(red[:2])             # u_k . A u_k and |u_k|^2 together
+            e.phase_recur_lazy(red)
+            self.k += 1
+            return
         self.comm.all_reduce_sum(red[:1])                 # alpha
         if self.reorth == "selective":
             self.ab[0:1].copy_(red[:1])
@@ -300,6 +310,12 @@ class DistLanczos:
             self.step()
 
     def history(self):
+        if self.lazy and self.k > 0 and self._closed_k != self.k:
+            # beta of the last iteration is the norm of the vector it left behind
+            self.engine.phase_lazy_norm(self.red)
+            self.comm.all_reduce_sum(self.red[:1])
+            self.engine.phase_lazy_close(self.red)
+            self._closed_k = self.k
         return self.engine.history(self.k)
 
 
@@ -336,6 +352,15 @@ class _GpuPhaseEngine:
 
     def phase_scale(self, red):
         self.e.phase_scale(red.data_ptr())
+
+    def phase_recur_lazy(self, red):
+        self.e.phase_recur_lazy(red.data_ptr())
+
+    def phase_lazy_norm(self, red):
+        self.e.phase_lazy_norm(red.data_ptr())
+
+    def phase_lazy_close(self, red):
+        self.e.phase_lazy_close(red.data_ptr())
 
     def history(self, count):
         return self.e.history(count)
@@ -464,7 +489,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             "config": {
                 "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), {K} Lanczos steps from a fixed "
                             f"N(0,1) start vector, reorth={args.reorth}, row-partitioned over {world} GPUs "
-                            f"({runner.plan.mode} exchange + 2 all-reduces per step)",
+                            f"({runner.plan.mode} exchange + {1 if runner.lazy else 2} all-reduce(s) per step)",
                 "reorth": args.reorth,
                 "exchange": runner.plan.mode,
                 "parallelism": f"row-partition x{world}",

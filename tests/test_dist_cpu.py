@@ -55,12 +55,18 @@ class NumpyPhaseEngine:
         self.alpha_hist, self.beta_hist = [], []
 
     def export_vector(self, k, dst):
-        dst.copy_(torch.from_numpy(self.V[k]))
+        dst.copy_(torch.from_numpy(self.V[k % 3] if self.reorth == "none" else self.V[k]))
 
     def _range(self):
         return {"none": 0, "cuda_compat": max(self.k - 2, 0), "selective": self.k + 1}.get(self.reorth, self.k)
 
     def phase_spmv(self, red):
+        if self.reorth == "none":
+            k = self.k
+            self.V[(k + 1) % 3] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
+            red[0] = float(self.V[k % 3] @ self.V[(k + 1) % 3])
+            red[1] = self.last_norm2 if k > 0 else 0.0
+            return
         self.V[self.k + 1] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
         red[0] = float(self.V[self.k] @ self.V[self.k + 1])
 
@@ -95,6 +101,30 @@ class NumpyPhaseEngine:
             red[0] = max(float(red[nl]) - float(h @ h), 0.0)   # global already: red was reduced over ranks
         else:
             red[0] = float(w @ w)
+
+    # reorth=none: the engine's deferred normalisation, u_k = beta_{k-1} v_k
+    def phase_recur_lazy(self, red):
+        k = self.k
+        dot, norm2 = float(red[0]), float(red[1])
+        beta_km1 = np.sqrt(norm2) if k > 0 else 0.0
+        s_k = 1.0 / beta_km1 if k > 0 else 1.0
+        s_km1 = 1.0 / self.beta_hist[k - 2] if k > 1 else 1.0
+        alpha = s_k * s_k * dot
+        w = self.V[(k + 1) % 3]
+        if k > 0:
+            w[:] = (s_k * w - beta_km1 * s_km1 * self.V[(k - 1) % 3]) - alpha * s_k * self.V[k % 3]
+            self.beta_hist.append(beta_km1)
+        else:
+            w[:] = w - alpha * s_k * self.V[0]
+        self.alpha_hist.append(alpha)
+        self.last_norm2 = float(w @ w)
+        self.k += 1
+
+    def phase_lazy_norm(self, red):
+        red[0] = self.last_norm2
+
+    def phase_lazy_close(self, red):
+        self.beta_hist.append(float(np.sqrt(red[0])))
 
     def phase_scale(self, red):
         beta = float(np.sqrt(red[0]))
