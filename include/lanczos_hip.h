@@ -168,7 +168,26 @@ typedef struct lanczos_hip_options {
     int64_t row_begin;
     int64_t n_ext;
     double *x_ext; /* device pointer, n_ext doubles, owned by the caller */
+    /*
+     * Row-partitioned use without the gather buffer: the caller owns the Krylov basis.
+     * basis points to nvec * basis_ld doubles of device memory (nvec = 3 with
+     * LANCZOS_HIP_REORTH_NONE, else max_iter), vector j at basis + slot(j) * basis_ld with
+     * slot(j) = j % 3 resp. j.  The SpMV of iteration k reads x straight from vector k:
+     * entries [0, n) are the slab itself, and column indices >= lanczos_hip_gather_base(n)
+     * address the tail of the same vector, which the host fills with the remote entries
+     * (halo exchange) before lanczos_hip_phase_spmv -- no copy of the vector per iteration.
+     * n_ext = gather base + number of remote entries <= basis_ld; basis_ld even, basis
+     * 16-byte aligned.  Entries [n, gather base) must stay zero; the engine clears the whole
+     * basis at lanczos_hip_set_start and its vector kernels never touch the tails.
+     * x_ext must be NULL.
+     */
+    double *basis;
+    int64_t basis_ld;
 } lanczos_hip_options;
+
+/* First x index of the remote entries for an engine created with options.basis:
+ * n rounded up to the engine's vector tile (2048 doubles). */
+int64_t lanczos_hip_gather_base(int64_t n);
 
 /*
  * Upload a CRS matrix (the three arrays of Mat_Crs, src/crs.h:4-21) and

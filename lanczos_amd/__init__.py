@@ -48,7 +48,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_size_t), ("device", C.c_int), ("stream", C.c_void_p),
                 ("reorth", C.c_int), ("spmv_kernel", C.c_int), ("profile", C.c_int),
                 ("n_global", C.c_int64), ("row_begin", C.c_int64), ("n_ext", C.c_int64),
-                ("x_ext", C.c_void_p)]
+                ("x_ext", C.c_void_p), ("basis", C.c_void_p), ("basis_ld", C.c_int64)]
 
 
 REORTH = {"full": 0, "cuda_compat": 1, "none": 2, "mgs": 3, "full2": 4, "selective": 5}
@@ -108,6 +108,8 @@ _hip.lanczos_hip_spmv_name.argtypes = [C.c_void_p]
 _hip.lanczos_hip_spmv_name.restype = C.c_char_p
 _hip.lanczos_hip_tridiag_eigs.argtypes = [_dp, _dp, C.c_int, C.c_int, _dp]
 _hip.lanczos_hip_tridiag_eigs.restype = C.c_int
+_hip.lanczos_hip_gather_base.argtypes = [C.c_int64]
+_hip.lanczos_hip_gather_base.restype = C.c_int64
 _hip.lanczos_hip_last_error.argtypes = []
 _hip.lanczos_hip_last_error.restype = C.c_char_p
 for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip_phase_scale",
@@ -464,12 +466,13 @@ class Engine:
 
     def __init__(self, a: CrsMatrix, max_iter: int, reorth: str = "full", spmv: str = "auto",
                  profile: bool = False, device: int = -1, stream: int | None = None,
-                 n_global: int = 0, row_begin: int = 0, n_ext: int = 0, x_ext: int | None = None):
+                 n_global: int = 0, row_begin: int = 0, n_ext: int = 0, x_ext: int | None = None,
+                 basis: int | None = None, basis_ld: int = 0):
         self._h = C.c_void_p(None)
         self.n = a.dimension
         self.max_iter = max_iter
         opt = Options(C.sizeof(Options), device, stream, REORTH[reorth], SPMV[spmv], int(profile),
-                      n_global, row_begin, n_ext, x_ext)
+                      n_global, row_begin, n_ext, x_ext, basis, basis_ld)
         _check(_hip.lanczos_hip_create(C.byref(self._h), a.dimension, a.length,
                                        a.row_head_indexes.ctypes.data_as(_ip),
                                        a.column_index.ctypes.data_as(_ip),
@@ -641,6 +644,11 @@ class Engine:
         _check(_hip.lanczos_hip_history(self._h, alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp), count),
                "lanczos_hip_history")
         return alpha, beta
+
+
+def gather_base(n: int) -> int:
+    """First x index of the remote entries of an engine that owns no basis (options.basis)."""
+    return int(_hip.lanczos_hip_gather_base(n))
 
 
 def ritz_values(alpha, beta, steps: int, nth: int) -> np.ndarray:

@@ -323,7 +323,7 @@ int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, co
     memset(&opt, 0, sizeof opt);
     opt.device = -1;
     if (opt_in) memcpy(&opt, opt_in, std::min(sizeof opt, opt_in->struct_size));
-    if (opt.x_ext) return lz::fail("lanczos_hip_block_create: row-partitioned matrices are not supported");
+    if (opt.x_ext || opt.basis) return lz::fail("lanczos_hip_block_create: row-partitioned matrices are not supported");
     const int want_profile = opt.profile;
     opt.struct_size = sizeof opt;
     opt.reorth = LANCZOS_HIP_REORTH_NONE;  // the base engine only holds the matrix:

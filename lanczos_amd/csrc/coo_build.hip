@@ -172,7 +172,7 @@ int Engine::create_from_coo(Engine **out, const Mat_Coo *coo, int swap, int max_
     if (coo->dimension > (size_t)INT32_MAX)
         return fail("Matrix dimension too large for HIP CRS (dim=%zu)", coo->dimension);
     if (max_iter < 2) return fail("max_iter must be >= 2");
-    if (opt.x_ext) return fail("lanczos_hip_create_from_coo: row-partitioned engines take CRS slabs");
+    if (opt.x_ext || opt.basis) return fail("lanczos_hip_create_from_coo: row-partitioned engines take CRS slabs");
     Engine *e = new Engine();
     int rc = e->setup_device(opt, (int64_t)coo->dimension, (int64_t)coo->dimension, (int64_t)coo->length, max_iter);
     if (rc == 0) rc = e->build_from_coo(coo->data, (int64_t)coo->length, swap);

@@ -22,6 +22,9 @@ struct Engine {
     int64_t row_begin = 0;
     int64_t nnz = 0;
     int64_t ldv = 0;       // doubles between consecutive basis vectors (zero padded)
+    int64_t npad = 0;      // n rounded up to whole vector tiles: what the vector kernels sweep
+    bool own_V = true;     // false: the caller's memory (options.basis), with room for remote entries behind npad
+    bool slab = false;     // row-partitioned engine (gather buffer or caller-owned basis)
     int max_iter = 0;
     int nvec = 0;          // resident basis vectors (max_iter, or a ring of 3)
     int reorth = 0;

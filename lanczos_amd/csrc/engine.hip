@@ -115,10 +115,21 @@ int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, cons
     if (n > (int64_t)INT32_MAX)
         return fail("Matrix dimension too large for HIP CRS (dim=%lld)", (long long)n);
     if (max_iter < 2) return fail("max_iter must be >= 2");
-    const bool dist = opt.x_ext != nullptr;
+    const bool dist = opt.x_ext != nullptr || opt.basis != nullptr;
     const int64_t n_ext = dist ? opt.n_ext : n;
     if (dist && (n_ext <= 0 || n_ext > (int64_t)INT32_MAX))
         return fail("lanczos_hip_create: bad n_ext=%lld", (long long)n_ext);
+    if (opt.basis) {
+        const int64_t base = lanczos_hip_gather_base(n);
+        if (opt.x_ext) return fail("lanczos_hip_create: options.basis and options.x_ext exclude each other");
+        if (opt.basis_ld < base || opt.basis_ld < n_ext || (opt.basis_ld & 1) || ((uintptr_t)opt.basis & 15))
+            return fail("lanczos_hip_create: basis_ld=%lld must be even and >= max(%lld, n_ext=%lld), basis 16-byte aligned",
+                        (long long)opt.basis_ld, (long long)base, (long long)n_ext);
+        // a column index may address the slab [0, n) or the tail [base, n_ext), never the zero padding between
+        int gap = 0;
+        for (int64_t j = 0; j < nnz; j++) gap |= (ci[j] >= n && ci[j] < base);
+        if (gap) return fail("lanczos_hip_create: column index inside the padding [%lld, %lld)", (long long)n, (long long)base);
+    }
     // The kernels trust these arrays; check them here, once, on the host.
     if (rp[0] != 0 || rp[n] != nnz)
         return fail("lanczos_hip_create: row_head_indexes[0]=%lld, [n]=%lld, nnz=%lld", (long long)rp[0],
@@ -150,6 +161,12 @@ int Engine::setup_device(const lanczos_hip_options &opt, int64_t n_, int64_t n_e
     reorth = opt.reorth;
     profile = opt.profile != 0;
     x_ext = opt.x_ext;
+    slab = opt.x_ext != nullptr || opt.basis != nullptr;
+    if (opt.basis) {
+        d_V = opt.basis;
+        ldv = opt.basis_ld;
+        own_V = false;
+    }
     n_global = opt.n_global ? opt.n_global : n;
     row_begin = opt.row_begin;
     if (opt.device >= 0) {
@@ -322,18 +339,20 @@ int Engine::choose_spmv(int requested) {
 
 int Engine::alloc_state() {
     // ---- Krylov basis: every vector padded with zeros to whole tiles
-    ldv = round_up(n, 2 * kTileV2);
+    npad = round_up(n, 2 * kTileV2);
     nvec = (reorth == LANCZOS_HIP_REORTH_NONE) ? 3 : max_iter;
-    const size_t vbytes = sizeof(double) * (size_t)ldv * (size_t)nvec;
-    HIP_TRY(hipMalloc(&d_V, vbytes));
-    HIP_TRY(hipMemsetAsync(d_V, 0, vbytes, stream));
+    if (own_V) {
+        ldv = npad;
+        HIP_TRY(hipMalloc(&d_V, sizeof(double) * (size_t)ldv * (size_t)nvec));
+    }
+    HIP_TRY(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)ldv * (size_t)nvec, stream));
 
     // ---- small buffers
     HIP_TRY(hipMalloc(&d_partials, sizeof(double) * max_blocks));
     HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
     HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
-    lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && x_ext == nullptr;
-    lazy_slab = reorth == LANCZOS_HIP_REORTH_NONE && x_ext != nullptr;
+    lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && !slab;
+    lazy_slab = reorth == LANCZOS_HIP_REORTH_NONE && slab;
     hstride = max_blocks;
     const int hl = std::min(max_iter, kMaxDotsSegment);
     HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)hstride * (size_t)hl));
@@ -373,7 +392,7 @@ Engine::~Engine() {
     (void)hipFree(d_val);
     (void)hipFree(d_col);
     (void)hipFree(d_rp);
-    (void)hipFree(d_V);
+    if (own_V) (void)hipFree(d_V);
     (void)hipFree(d_partials);
     (void)hipFree(d_norm_parts);
     (void)hipFree(d_hpart);
@@ -392,13 +411,13 @@ Engine::~Engine() {
 // launches
 // ---------------------------------------------------------------------------
 int Engine::vec_blocks() const {
-    const int64_t n2 = ldv / 2;
+    const int64_t n2 = npad / 2;
     return (int)std::min<int64_t>(max_blocks, (n2 + kBlock - 1) / kBlock);
 }
 
 int Engine::tile_blocks() const {
     // 4 workgroups per CU: measured best for the basis-streaming kernels
-    const int64_t tiles = (ldv / 2) / kTileV2;
+    const int64_t tiles = (npad / 2) / kTileV2;
     return (int)std::min<int64_t>(max_blocks / 2, std::max<int64_t>(tiles, 1));
 }
 
@@ -523,7 +542,7 @@ int Engine::launch_dots(int l0, int l1, double *red_out) {
         {
             ProfScope ps(this, LANCZOS_HIP_K_DOTS, 8.0 * (double)n * nl + 8.0 * (double)n);
             hipLaunchKernelGGL(k_dots, dim3(blocks), dim3(kBlock), sizeof(double) * kWavesPerBlock * nl, stream,
-                               (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), ldv / 2,
+                               (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), npad / 2,
                                d_hpart, hstride);
         }
         {
@@ -541,7 +560,7 @@ int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
     *nparts = blocks;
     ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (l1 - l0) + 16.0 * (double)n);
     hipLaunchKernelGGL(k_update, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
-                       (double2 *)vec(k + 1), ldv / 2, h, norm_parts(k));
+                       (double2 *)vec(k + 1), npad / 2, h, norm_parts(k));
     norm_count = blocks;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -559,12 +578,12 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
     const int blocks = vec_blocks();
     if (normalise) {
         hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)vec(0),
-                           (const double2 *)vec(0), ldv / 2, d_partials);
+                           (const double2 *)vec(0), npad / 2, d_partials);
         hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kBlock), 0, stream, (const double *)d_partials, blocks, d_red);
-        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), ldv / 2,
+        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), npad / 2,
                            (const double *)d_red, 0.0);
     } else {
-        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), ldv / 2,
+        hipLaunchKernelGGL(k_scal_mul, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(0), npad / 2,
                            (const double *)nullptr, scale);
     }
     HIP_TRY(hipMemsetAsync(d_scal, 0, sizeof(double) * 8, stream));
@@ -620,7 +639,7 @@ int Engine::phase_recur_lazy(double *red) {
     {
         ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
         hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
-                           (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, k,
+                           (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, k,
                            (const double *)red, 1, (const double *)(red + 1), 1, norm_parts(k), d_alpha, d_beta,
                            h_hist);
     }
@@ -651,7 +670,7 @@ int Engine::launch_recur(const double *alpha_parts, int alpha_cnt) {
     ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
     double *ahost = h_hist ? h_hist + 2 * (size_t)k : nullptr;
     hipLaunchKernelGGL(k_recur, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
-                       (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, alpha_parts,
+                       (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, alpha_parts,
                        alpha_cnt, (const double *)(d_scal + 1), norm_parts(k), d_alpha + k, ahost);
     norm_count = blocks;
     HIP_TRY(hipGetLastError());
@@ -664,7 +683,7 @@ int Engine::launch_scale(const double *parts, int cnt) {
     {
         ProfScope ps(this, LANCZOS_HIP_K_SCALE, 16.0 * (double)n);
         double *bhost = h_hist ? h_hist + 2 * (size_t)k + 1 : nullptr;
-        hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1), ldv / 2, parts, cnt,
+        hipLaunchKernelGGL(k_scale, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1), npad / 2, parts, cnt,
                            d_scal + 1, d_beta + k, bhost);
     }
     HIP_TRY(hipGetLastError());
@@ -747,7 +766,7 @@ int Engine::enqueue_iteration() {
         {
             ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
             hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
-                               (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), ldv / 2, k,
+                               (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, k,
                                (const double *)d_partials, alpha_count, (const double *)norm_parts(k - 1), norm_count,
                                norm_parts(k), d_alpha, d_beta, h_hist);
         }
@@ -855,7 +874,7 @@ int Engine::combine(int m, int count, const double *coef_host, double *out_dev, 
             ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (m + nj));
             hipLaunchKernelGGL((k_combine<J>), dim3(tile_blocks()), dim3(kBlock), 0, stream, (const double2 *)d_V,
                                ldv / 2, m, (const double *)d_coef, (double2 *)(out_dev + (size_t)i0 * out_ld),
-                               out_ld / 2, nj, ldv / 2);
+                               out_ld / 2, nj, npad / 2);
             st = hipGetLastError();
         }
         if (st == hipSuccess) st = hipStreamSynchronize(stream);  // c is reused by the next group
@@ -873,7 +892,7 @@ int Engine::restart(int p, const double *coef_host, double last_coupling) {
     if (!started) return fail("lanczos_hip_restart: no run to restart");
     if (reorth != LANCZOS_HIP_REORTH_FULL && reorth != LANCZOS_HIP_REORTH_FULL2 && reorth != LANCZOS_HIP_REORTH_MGS)
         return fail("lanczos_hip_restart: needs reorthogonalisation against the whole basis (full, full2 or mgs)");
-    if (x_ext) return fail("lanczos_hip_restart: not available on a row-partitioned engine");
+    if (slab) return fail("lanczos_hip_restart: not available on a row-partitioned engine");
     if (p < 1 || p >= k || !coef_host) return fail("lanczos_hip_restart: keep=%d of %d iterations", p, k);
     HIP_TRY(hipSetDevice(device));
     double *d_tmp = nullptr;
@@ -975,7 +994,7 @@ int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, d
 int lanczos_hip_set_start_seed(lanczos_hip_engine *e, uint64_t seed) {
     if (!e) return lz::fail("lanczos_hip_set_start_seed: NULL engine");
     Engine *g = E(e);
-    if (g->x_ext) return lz::fail("lanczos_hip_set_start_seed: row-partitioned engines need a global norm; use lanczos_hip_gaussian_fill + lanczos_hip_set_start_scaled");
+    if (g->slab) return lz::fail("lanczos_hip_set_start_seed: row-partitioned engines need a global norm; use lanczos_hip_gaussian_fill + lanczos_hip_set_start_scaled");
     std::vector<double> v((size_t)g->n);
     lanczos_hip_gaussian_fill(seed, g->row_begin, g->n, v.data());
     return g->set_start(v.data(), true, 1.0);
@@ -983,7 +1002,7 @@ int lanczos_hip_set_start_seed(lanczos_hip_engine *e, uint64_t seed) {
 
 int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out) {
     if (!e) return lz::fail("lanczos_hip_run: NULL engine");
-    if (E(e)->x_ext) return lz::fail("lanczos_hip_run: row-partitioned engines are driven phase by phase");
+    if (E(e)->slab) return lz::fail("lanczos_hip_run: row-partitioned engines are driven phase by phase");
     return E(e)->run(steps, alpha_out, beta_out);
 }
 
@@ -1037,7 +1056,7 @@ int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *e
                              double *residual_est) {
     if (!eh || !eig || steps < 1 || m < 1) return lz::fail("lanczos_hip_ritz_vectors: bad argument");
     Engine *e = E(eh);
-    if (e->reorth == LANCZOS_HIP_REORTH_NONE || e->x_ext)
+    if (e->reorth == LANCZOS_HIP_REORTH_NONE || e->slab)
         return lz::fail("lanczos_hip_ritz_vectors: needs the whole basis resident on one GPU (not reorth=none, not a row slab)");
     if (steps > e->k) return lz::fail("lanczos_hip_ritz_vectors: only %d iterations done", e->k);
     if (m > steps) m = steps;
@@ -1109,6 +1128,7 @@ int lanczos_hip_phase_lazy_close(lanczos_hip_engine *e, double *red) {
     if (!e || !red) return lz::fail("lanczos_hip_phase_lazy_close: NULL argument");
     return E(e)->phase_lazy_close(red);
 }
+int64_t lanczos_hip_gather_base(int64_t n) { return lz::round_up(n, 2 * lz::kTileV2); }
 int lanczos_hip_export_vector(lanczos_hip_engine *e, int k, double *dst_device) {
     if (!e || !dst_device || k < 0) return lz::fail("lanczos_hip_export_vector: bad argument");
     Engine *g = E(e);

@@ -52,6 +52,9 @@ class SlabPlan:
     halo_lo: int         # entries needed from the end of the previous slab
     halo_hi: int         # entries needed from the start of the next slab
     column_index: np.ndarray  # remapped into [0, n_ext)
+    remote_base: int = -1     # halo form: index of the first remote entry (n_local, or past the padding
+                              # of the vector itself when in_place)
+    in_place: bool = False    # the remote entries live in the tail of the basis vector the SpMV reads
 
 
 def needed_halo(cols: np.ndarray, row_begin: int, row_end: int) -> tuple[int, int]:
@@ -63,25 +66,30 @@ def needed_halo(cols: np.ndarray, row_begin: int, row_end: int) -> tuple[int, in
     return max(row_begin - lo, 0), max(hi - (row_end - 1), 0)
 
 
-def plan_slab(cols: np.ndarray, bounds: list[int], rank: int, mode: str) -> SlabPlan:
+def plan_slab(cols: np.ndarray, bounds: list[int], rank: int, mode: str, remote_base: int = -1) -> SlabPlan:
     """Remap global column indices for `mode`.
 
-    halo:      x_ext = [own slab | tail of slab rank-1 (halo_lo) | head of slab rank+1 (halo_hi)]
+    halo:      x_ext = [own slab | tail of slab rank-1 (halo_lo) | head of slab rank+1 (halo_hi)];
+               with remote_base >= n_local the two remote parts start there instead of at n_local
+               (the gap stays unaddressed): the layout of a basis vector with the remote entries
+               in its own tail
     allgather: x_ext = the whole vector in slab order, every slab padded to the longest one
     """
     world = len(bounds) - 1
     r0, r1 = bounds[rank], bounds[rank + 1]
     n_local = r1 - r0
     if mode == "halo":
+        base = n_local if remote_base < 0 else remote_base
+        assert base >= n_local
         hlo, hhi = needed_halo(cols, r0, r1)
         out = np.empty_like(cols)
         own = (cols >= r0) & (cols < r1)
         below = cols < r0
         above = cols >= r1
         out[own] = cols[own] - r0
-        out[below] = n_local + (cols[below] - (r0 - hlo))
-        out[above] = n_local + hlo + (cols[above] - r1)
-        return SlabPlan("halo", n_local, n_local + hlo + hhi, r0, hlo, hhi, out)
+        out[below] = base + (cols[below] - (r0 - hlo))
+        out[above] = base + hlo + (cols[above] - r1)
+        return SlabPlan("halo", n_local, base + hlo + hhi, r0, hlo, hhi, out, base, remote_base >= 0)
     pad = max(bounds[p + 1] - bounds[p] for p in range(world))
     owner = np.searchsorted(np.asarray(bounds[1:]), cols, side="right")
     out = owner * pad + (cols - np.asarray(bounds)[owner])
@@ -211,9 +219,20 @@ class DistLanczos:
         self.comm, self.torch, self.device = comm, torch, device
         self.plan, self.bounds, self.max_iter, self.reorth = plan, bounds, max_iter, reorth
         self.rank, self.world = comm.rank, comm.world
-        self.x_ext = torch.zeros(plan.n_ext, dtype=torch.float64, device=device)
         self.red = torch.zeros(max_iter + 8, dtype=torch.float64, device=device)
-        self.engine = make_engine(plan, self.x_ext, max_iter)
+        # in-place halo form: the basis lives here, in a tensor the collectives
+        # can address, and the remote entries are received straight into the tail of the vector the
+        # SpMV reads -- no gather buffer, no copy of the vector per iteration
+        self.in_place = plan.mode == "halo" and plan.in_place
+        if self.in_place:
+            self.nvec = 3 if reorth == "none" else max_iter
+            self.ld = -(-plan.n_ext // 2048) * 2048
+            self.basis = torch.zeros(self.nvec, self.ld, dtype=torch.float64, device=device)
+            self.x_ext = None
+            self.engine = make_engine(plan, self.basis, max_iter)
+        else:
+            self.x_ext = torch.zeros(plan.n_ext, dtype=torch.float64, device=device)
+            self.engine = make_engine(plan, self.x_ext, max_iter)
         self.k = 0
         self.reorth_steps = 0
         # no reorthogonalisation: unnormalised basis, one reduction of two doubles per iteration
@@ -256,13 +275,17 @@ class DistLanczos:
             if self.world > 1:
                 self.comm.all_gather_into(self.x_ext, self.x_ext[self.rank * self.pad:(self.rank + 1) * self.pad])
             return
-        self.engine.export_vector(self.k, self.x_ext[:n])
+        if self.in_place:
+            x, base = self.basis[self.k % 3 if self.nvec == 3 else self.k], p.remote_base
+        else:
+            x, base = self.x_ext, n
+            self.engine.export_vector(self.k, x[:n])
         if self.world == 1:
             return
-        send_lo = self.x_ext[:self.send_lo] if self.send_lo else None
-        send_hi = self.x_ext[n - self.send_hi:n] if self.send_hi else None
-        recv_lo = self.x_ext[n:n + p.halo_lo] if p.halo_lo else None
-        recv_hi = self.x_ext[n + p.halo_lo:n + p.halo_lo + p.halo_hi] if p.halo_hi else None
+        send_lo = x[:self.send_lo] if self.send_lo else None
+        send_hi = x[n - self.send_hi:n] if self.send_hi else None
+        recv_lo = x[base:base + p.halo_lo] if p.halo_lo else None
+        recv_hi = x[base + p.halo_lo:base + p.halo_lo + p.halo_hi] if p.halo_hi else None
         self.comm.neighbour_exchange(send_lo, recv_lo, send_hi, recv_hi)
 
     # -- one iteration (reference src/lanczos.c:109-190, split at the reductions) --
@@ -329,8 +352,13 @@ class _GpuPhaseEngine:
                  profile=False):
         self.la = la
         mat = la.CrsMatrix(a_local.values, plan.column_index, a_local.row_head_indexes)
-        self.e = la.Engine(mat, max_iter, reorth=reorth, spmv=spmv, profile=profile, stream=stream,
-                           n_global=n_global, row_begin=plan.row_begin, n_ext=plan.n_ext, x_ext=x_ext.data_ptr())
+        if x_ext.dim() == 2:   # the caller's basis, remote entries in the tails of its vectors
+            self.e = la.Engine(mat, max_iter, reorth=reorth, spmv=spmv, profile=profile, stream=stream,
+                               n_global=n_global, row_begin=plan.row_begin, n_ext=plan.n_ext,
+                               basis=x_ext.data_ptr(), basis_ld=x_ext.shape[1])
+        else:
+            self.e = la.Engine(mat, max_iter, reorth=reorth, spmv=spmv, profile=profile, stream=stream,
+                               n_global=n_global, row_begin=plan.row_begin, n_ext=plan.n_ext, x_ext=x_ext.data_ptr())
 
     def set_start_scaled(self, v0, scale):
         self.e.set_start_scaled(v0, scale)
@@ -377,12 +405,13 @@ def choose_mode(cols, bounds, rank, comm, want="auto"):
 
 
 def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mode="auto", spmv="auto",
-                   profile=False):
+                   profile=False, in_place=True):
     """a_local: this rank's slab as a CrsMatrix with GLOBAL column indices."""
     rank = comm.rank
     device = torch.device("cuda", torch.cuda.current_device())
     mode = choose_mode(a_local.column_index, bounds, rank, comm, mode)
-    plan = plan_slab(a_local.column_index, bounds, rank, mode)
+    n_local = bounds[rank + 1] - bounds[rank]
+    plan = plan_slab(a_local.column_index, bounds, rank, mode, la.gather_base(n_local) if in_place else -1)
     # One side stream carries the engine's kernels AND torch's collectives/copies, so
     # they are ordered without host syncs.  It must not be the legacy default stream:
     # its handle is 0, which the C ABI reads as "create a private stream".
@@ -513,13 +542,19 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
     p2 = r2.engine.e.profile()
     if rank == 0:
         b = algorithmic_bytes(n, nnz)
+        # bytes of the matrix format in use on rank 0's slab (CRS or row-pattern dictionary), times the ranks
+        fmt_iter = (p2["spmv"]["bytes"] / steps2 + 64.0 * (bounds[1] - bounds[0])) * world
         out["spmv_vector_step"] = {
             "iters_per_s": steps2 / dt2,
             "ms_per_iter": dt2 / steps2 * 1e3,
-            "algorithmic_bytes_per_iter": b["iter"],
-            "frac_of_hbm_peak": b["iter"] * steps2 / dt2 / 1e9 / (hbm_peak * world),
+            "spmv_kernel": r2.engine.e.spmv_name,
+            "format_bytes_per_iter": fmt_iter,
+            "frac_of_hbm_peak": fmt_iter * steps2 / dt2 / 1e9 / (hbm_peak * world),
+            "crs_algorithmic_bytes_per_iter": b["iter"],
+            "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt2 / 1e9,
             "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
             "exchange": r2.plan.mode,
+            "all_reduces_per_step": 1 if r2.lazy else 2,
         }
     del r2
     torch.cuda.empty_cache()
@@ -573,6 +608,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                 "iters_per_s": steps2 / dt4,
                 "ms_per_iter": dt4 / steps2 * 1e3,
                 "spmv_kernel": r4.engine.e.spmv_name,
+                "format_bytes_per_iter": (p4["spmv"]["bytes"] / steps2 + 64.0 * (bb[1] - bb[0])) * world,
                 "crs_algorithmic_bytes_per_iter": b["iter"],
                 "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt4 / 1e9,
                 "spmv_avg_ms_rank0": p4["spmv"]["ms"] / steps2,

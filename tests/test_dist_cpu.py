@@ -37,65 +37,75 @@ def test_partition_and_plans():
 
 
 class NumpyPhaseEngine:
-    """Phase interface of lanczos_amd.Engine on numpy; mirrors the engine's semantics."""
+    """Phase interface of lanczos_amd.Engine on numpy; mirrors the engine's semantics.  x_ext is the
+    gather buffer (1-D) or the caller-owned basis with the remote entries in each vector's tail (2-D)."""
 
     def __init__(self, oracle, a_vals, a_head, plan, x_ext, max_iter, reorth):
         self.oracle = oracle
         self.vals, self.head, self.cols = a_vals, a_head, plan.column_index
-        self.n, self.x_ext, self.reorth = plan.n_local, x_ext, reorth
-        self.V = np.zeros((max_iter, self.n))
+        self.n, self.reorth = plan.n_local, reorth
+        self.ring = reorth == "none"
+        if x_ext.dim() == 2:
+            self.B, self.x_ext = x_ext.numpy(), None          # shares the tensor's memory
+            assert self.B.shape[0] == (3 if self.ring else max_iter)
+        else:
+            self.B, self.x_ext = np.zeros((3 if self.ring else max_iter, self.n)), x_ext
         self.k = 0
         self.beta_prev = 0.0
         self.alpha_hist, self.beta_hist = [], []
 
+    def vec(self, j):
+        return self.B[j % 3 if self.ring else j][:self.n]
+
     def set_start_scaled(self, v0, scale):
-        self.V[:] = 0
-        self.V[0] = scale * np.asarray(v0)
+        self.B[:] = 0
+        self.vec(0)[:] = scale * np.asarray(v0)
         self.k, self.beta_prev = 0, 0.0
         self.alpha_hist, self.beta_hist = [], []
 
     def export_vector(self, k, dst):
-        dst.copy_(torch.from_numpy(self.V[k % 3] if self.reorth == "none" else self.V[k]))
+        dst.copy_(torch.from_numpy(self.vec(k)))
 
     def _range(self):
         return {"none": 0, "cuda_compat": max(self.k - 2, 0), "selective": self.k + 1}.get(self.reorth, self.k)
 
+    def _basis(self, nl):
+        return self.B[:nl, :self.n]
+
     def phase_spmv(self, red):
-        if self.reorth == "none":
-            k = self.k
-            self.V[(k + 1) % 3] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
-            red[0] = float(self.V[k % 3] @ self.V[(k + 1) % 3])
+        k = self.k
+        x = self.x_ext.numpy() if self.x_ext is not None else self.B[k % 3 if self.ring else k]
+        self.vec(k + 1)[:] = self.oracle.matvec_crs(self.head, self.cols, self.vals, x)
+        red[0] = float(self.vec(k) @ self.vec(k + 1))
+        if self.ring:
             red[1] = self.last_norm2 if k > 0 else 0.0
-            return
-        self.V[self.k + 1] = self.oracle.matvec_crs(self.head, self.cols, self.vals, self.x_ext.numpy())
-        red[0] = float(self.V[self.k] @ self.V[self.k + 1])
 
     def phase_recur(self, red):
         alpha = float(red[0])
         self.alpha_hist.append(alpha)
-        w = self.V[self.k + 1]
-        prev = self.V[self.k - 1] if self.k > 0 else 0.0
-        w[:] = (w - self.beta_prev * prev) - alpha * self.V[self.k]
+        w = self.vec(self.k + 1)
+        prev = self.vec(self.k - 1) if self.k > 0 else 0.0
+        w[:] = (w - self.beta_prev * prev) - alpha * self.vec(self.k)
         nl = self._range()
         if nl == 0 or self.reorth == "selective":
             red[0] = float(w @ w)
             return 1, True
-        red[:nl] = torch.from_numpy(self.V[:nl] @ w)
+        red[:nl] = torch.from_numpy(self._basis(nl) @ w)
         red[nl] = float(w @ w)
         self.red_has_norm = True
         return nl + 1, False
 
     def phase_dots(self, red):
         nl = self._range()
-        red[:nl] = torch.from_numpy(self.V[:nl] @ self.V[self.k + 1])
+        red[:nl] = torch.from_numpy(self._basis(nl) @ self.vec(self.k + 1))
         self.red_has_norm = False
         return nl
 
     def phase_update(self, red):
         nl = self._range()
-        w = self.V[self.k + 1]
+        w = self.vec(self.k + 1)
         h = red[:nl].numpy().copy()
-        w -= h @ self.V[:nl]
+        w -= h @ self._basis(nl)
         if getattr(self, "red_has_norm", False):
             self.red_has_norm = False
             red[0] = max(float(red[nl]) - float(h @ h), 0.0)   # global already: red was reduced over ranks
@@ -110,12 +120,12 @@ class NumpyPhaseEngine:
         s_k = 1.0 / beta_km1 if k > 0 else 1.0
         s_km1 = 1.0 / self.beta_hist[k - 2] if k > 1 else 1.0
         alpha = s_k * s_k * dot
-        w = self.V[(k + 1) % 3]
+        w = self.vec(k + 1)
         if k > 0:
-            w[:] = (s_k * w - beta_km1 * s_km1 * self.V[(k - 1) % 3]) - alpha * s_k * self.V[k % 3]
+            w[:] = (s_k * w - beta_km1 * s_km1 * self.vec(k - 1)) - alpha * s_k * self.vec(k)
             self.beta_hist.append(beta_km1)
         else:
-            w[:] = w - alpha * s_k * self.V[0]
+            w[:] = w - alpha * s_k * self.vec(0)
         self.alpha_hist.append(alpha)
         self.last_norm2 = float(w @ w)
         self.k += 1
@@ -128,7 +138,7 @@ class NumpyPhaseEngine:
 
     def phase_scale(self, red):
         beta = float(np.sqrt(red[0]))
-        self.V[self.k + 1] /= beta
+        self.vec(self.k + 1)[:] /= beta
         self.beta_prev = beta
         self.beta_hist.append(beta)
         self.k += 1
@@ -164,8 +174,9 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     cols = full.column_index[h[r0]:h[r1]].copy()
     head = (h[r0:r1 + 1] - h[r0]).copy()
     comm = ld.Comm(dist, torch, "cpu")
-    chosen = ld.choose_mode(cols, bounds, rank, comm, mode)
-    plan = ld.plan_slab(cols, bounds, rank, chosen)
+    in_place = mode.endswith("+")              # remote entries in the tails of the basis vectors
+    chosen = ld.choose_mode(cols, bounds, rank, comm, mode.rstrip("+"))
+    plan = ld.plan_slab(cols, bounds, rank, chosen, la.gather_base(r1 - r0) if in_place else -1)
 
     def make_engine(plan_, x_ext, max_iter):
         return NumpyPhaseEngine(oracle, vals, head, plan_, x_ext, max_iter, reorth)
@@ -195,6 +206,9 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     (2, "random", "auto", "full", "allgather", 25),
     (3, "random", "auto", "cuda_compat", "allgather", 25),
     (2, "lap2d", "auto", "selective", "halo", 150),
+    (2, "lap2d", "auto+", "full", "halo", 25),
+    (3, "lap2d", "auto+", "none", "halo", 25),
+    (2, "random", "auto+", "full", "allgather", 25),
 ])
 def test_partitioned_run_matches_single_process(world, kind, mode, reorth, expect_mode, steps):
     ctx = mp.get_context("spawn")
