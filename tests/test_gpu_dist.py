@@ -102,3 +102,36 @@ def test_bench_distributed_code_path_with_one_rank(gpu):
         alpha, beta = e.run(40)
     want = la.ritz_values(alpha, beta, 40, 4)
     assert np.max(np.abs(np.array(out["ritz_lowest4"]) - want) / want) < 1e-10
+
+
+def test_caller_owned_basis_is_validated(gpu):
+    """options.basis: leading dimension and column numbering are checked before anything is launched."""
+    import torch
+    import lanczos_amd as la
+    a = la.synth_laplacian(1, 3000)
+    base = la.gather_base(3000)
+    assert base == 4096
+    basis = torch.zeros(5, base + 2048, dtype=torch.float64, device="cuda")
+    with pytest.raises(la.LanczosHipError, match="basis_ld"):
+        la.Engine(a, 5, n_global=3000, n_ext=base, basis=basis.data_ptr(), basis_ld=base - 2)
+    with pytest.raises(la.LanczosHipError, match="basis_ld"):
+        la.Engine(a, 5, n_global=3000, n_ext=base + 10, basis=basis.data_ptr(), basis_ld=base + 2047)
+    cols = a.column_index.copy()
+    cols[5] = 3500                                   # inside the zero padding [n, gather base)
+    bad = la.CrsMatrix(a.values, cols, a.row_head_indexes)
+    with pytest.raises(la.LanczosHipError, match="padding"):
+        la.Engine(bad, 5, n_global=3000, n_ext=base + 10, basis=basis.data_ptr(), basis_ld=base + 2048)
+    with pytest.raises(la.LanczosHipError, match="exclude"):
+        la.Engine(a, 5, n_global=3000, n_ext=base, x_ext=basis.data_ptr(), basis=basis.data_ptr(), basis_ld=base)
+    # a well-formed one: no remote entries, the engine works in the caller's memory
+    with la.Engine(a, 5, reorth="full", n_global=3000, n_ext=base, basis=basis.data_ptr(), basis_ld=base + 2048) as e:
+        v0 = la.gaussian_fill(3, 0, 3000)
+        e.set_start_scaled(v0, 1.0 / float(np.linalg.norm(v0)))
+        red = torch.zeros(16, dtype=torch.float64, device="cuda")
+        e.phase_spmv(red.data_ptr())
+        torch.cuda.synchronize()
+        w = basis[1, :3000].cpu().numpy()
+        want = la.matvec_crs(a, v0 / np.linalg.norm(v0))
+        assert np.max(np.abs(w - want)) < 1e-14
+        assert abs(float(red[0]) - float(want @ (v0 / np.linalg.norm(v0)))) < 1e-12
+        assert not basis[:, 3000:].any()
