@@ -364,6 +364,21 @@ int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red);
  * lanczos_hip_phase_lazy_close records beta_{k-1} = sqrt(red[0]) for lanczos_hip_history.
  */
 int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red);
+/*
+ * lanczos_hip_phase_spmv in two parts, so that the exchange of the remote entries runs while the
+ * product does (engines with options.basis whose matrix took the dictionary SpMV:
+ * lanczos_hip_phase_spmv_can_overlap).  Rows [first_interior_row, end_interior_row) are the ones
+ * that read no remote entry.
+ *   lanczos_hip_phase_spmv_begin  may be enqueued while the tail of vector k is still being
+ *                                 received: w = A x for every row, but only the interior rows
+ *                                 count towards u_k . w
+ *   lanczos_hip_phase_spmv_end    once the receives are ordered before it on the stream: the
+ *                                 other rows again (plain row-wise kernel, src/crs.c:167-177),
+ *                                 then red[] as lanczos_hip_phase_spmv leaves it
+ */
+int lanczos_hip_phase_spmv_begin(lanczos_hip_engine *e, int64_t first_interior_row, int64_t end_interior_row);
+int lanczos_hip_phase_spmv_end(lanczos_hip_engine *e, double *red);
+int lanczos_hip_phase_spmv_can_overlap(const lanczos_hip_engine *e);
 int lanczos_hip_phase_lazy_norm(lanczos_hip_engine *e, double *red);
 int lanczos_hip_phase_lazy_close(lanczos_hip_engine *e, double *red);
 double *lanczos_hip_local_vector(lanczos_hip_engine *e, int k);

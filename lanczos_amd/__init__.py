@@ -116,6 +116,12 @@ for _name in ("lanczos_hip_phase_spmv", "lanczos_hip_phase_update", "lanczos_hip
               "lanczos_hip_phase_recur_lazy", "lanczos_hip_phase_lazy_norm", "lanczos_hip_phase_lazy_close"):
     getattr(_hip, _name).argtypes = [C.c_void_p, C.c_void_p]
     getattr(_hip, _name).restype = C.c_int
+_hip.lanczos_hip_phase_spmv_begin.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+_hip.lanczos_hip_phase_spmv_begin.restype = C.c_int
+_hip.lanczos_hip_phase_spmv_end.argtypes = [C.c_void_p, C.c_void_p]
+_hip.lanczos_hip_phase_spmv_end.restype = C.c_int
+_hip.lanczos_hip_phase_spmv_can_overlap.argtypes = [C.c_void_p]
+_hip.lanczos_hip_phase_spmv_can_overlap.restype = C.c_int
 _hip.lanczos_hip_phase_recur.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
 _hip.lanczos_hip_phase_recur.restype = C.c_int
 _hip.lanczos_hip_phase_dots.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
@@ -626,6 +632,17 @@ class Engine:
 
     def phase_scale(self, red: int):
         _check(_hip.lanczos_hip_phase_scale(self._h, red), "lanczos_hip_phase_scale")
+
+    def phase_spmv_begin(self, first_interior_row: int, end_interior_row: int):
+        _check(_hip.lanczos_hip_phase_spmv_begin(self._h, first_interior_row, end_interior_row),
+               "lanczos_hip_phase_spmv_begin")
+
+    def phase_spmv_end(self, red: int):
+        _check(_hip.lanczos_hip_phase_spmv_end(self._h, red), "lanczos_hip_phase_spmv_end")
+
+    @property
+    def can_overlap(self) -> bool:
+        return bool(_hip.lanczos_hip_phase_spmv_can_overlap(self._h))
 
     def phase_recur_lazy(self, red: int):
         _check(_hip.lanczos_hip_phase_recur_lazy(self._h, red), "lanczos_hip_phase_recur_lazy")

@@ -118,7 +118,7 @@ k_dict_verify(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
 // whose fill is still in flight, which is what the overlapping gathers of a stencil produce
 // (measured: the L1 sat in that stall 70 % of the time with direct gathers).
 // Workgroup b serves the b % 8-th eighth of the rows (b and b + 8 share an L2).
-// partials[b] = this workgroup's part of xdot . y.
+// partials[b] = this workgroup's part of xdot . y over the rows [dot_lo, dot_hi).
 constexpr int kDictRows = 4;
 constexpr int kDictLdsEntries = 1024;  // dictionary entries (pattern x position) copied to LDS (12 KiB)
 constexpr int kDictSpan = kBlock * kDictRows;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(kBlock)
 k_spmv_dict(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
             const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
             const double *__restrict__ x, const double *__restrict__ xdot, double *__restrict__ y,
-            double *__restrict__ partials) {
+            double *__restrict__ partials, int64_t dot_lo, int64_t dot_hi) {
     extern __shared__ double win[];  // kDictSpan + 2 * halo doubles, then (LDS_DICT) the dictionary
     __shared__ double red[kBlock / 64];
     double *s_val = win + kDictSpan + 2 * halo;
@@ -191,7 +191,10 @@ k_spmv_dict(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int 
             if (p[u] >= 0) {
                 const int64_t r = row0 + u * kBlock + threadIdx.x;
                 __builtin_nontemporal_store(sum[u], y + r);
-                acc += (xdot == x ? win[u * kBlock + (int)threadIdx.x + halo] : xdot[r]) * sum[u];
+                // rows outside [dot_lo, dot_hi) are recomputed later (their remote entries were still
+                // on their way): whatever they hold now must not reach the sum
+                const double t = (xdot == x ? win[u * kBlock + (int)threadIdx.x + halo] : xdot[r]) * sum[u];
+                acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
             }
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
@@ -344,7 +347,8 @@ int Engine::build_dict() {
     return 0;
 }
 
-int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts) {
+int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo, int64_t dot_hi) {
+    if (dot_hi < 0) dot_hi = n;
     const int64_t chunks = (n + kBlock * kDictRows - 1) / (kBlock * kDictRows);
     int blocks = (int)std::min<int64_t>(max_blocks, (chunks + 7) / 8 * 8);
     *nparts = blocks;
@@ -354,11 +358,11 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     if (dict_patterns * dict_stride <= kDictLdsEntries)
         hipLaunchKernelGGL((k_spmv_dict<true>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
-                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials);
+                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials, dot_lo, dot_hi);
     else
         hipLaunchKernelGGL((k_spmv_dict<false>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
-                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials);
+                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials, dot_lo, dot_hi);
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;

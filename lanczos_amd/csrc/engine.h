@@ -104,7 +104,7 @@ struct Engine {
     int choose_spmv(int requested);
     int build_dict();
     void free_dict();
-    int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts);
+    int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1);
     int build_panels(int bits);
     void free_panels();
     int launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts);
@@ -133,6 +133,10 @@ struct Engine {
     int phase_dots(double *red, int *n_red);
     int phase_update(double *red);
     int phase_scale(double *red);
+    int phase_spmv_begin(int64_t b_lo, int64_t b_hi);
+    int phase_spmv_end(double *red);
+    int launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, int *nparts);
+    int64_t pending_lo = -1, pending_hi = -1;  // rows [0, lo) and [hi, n) wait for phase_spmv_end
     int phase_recur_lazy(double *red);
     int phase_lazy_norm(double *red);
     int phase_lazy_close(double *red);

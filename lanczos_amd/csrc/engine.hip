@@ -348,7 +348,7 @@ int Engine::alloc_state() {
     HIP_TRY(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)ldv * (size_t)nvec, stream));
 
     // ---- small buffers
-    HIP_TRY(hipMalloc(&d_partials, sizeof(double) * max_blocks));
+    HIP_TRY(hipMalloc(&d_partials, sizeof(double) * 3 * max_blocks));  // one SpMV, or one plus two row ranges
     HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
     HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
     lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && !slab;
@@ -628,6 +628,70 @@ int Engine::phase_spmv(double *red) {
     if (int rc = launch_finalize(d_partials, alpha_count, red)) return rc;
     if (lazy_slab)  // the slab's part of |u_k|^2 rides along: one reduction over ranks per iteration
         return launch_finalize(norm_parts(k - 1), k > 0 ? norm_count : 0, red + 1);
+    return 0;
+}
+
+// Rows [r_a, r_b) of the product through the plain row-wise kernel (src/crs.c:167-177): the same
+// arrays with the row offsets, y and xdot shifted; parts_out receives the partials of xdot . y.
+int Engine::launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, int *nparts) {
+    *nparts = 0;
+    const int64_t rows = r_b - r_a;
+    if (rows <= 0) return 0;
+    const double *x = vec(k);
+    const double *xdot = vec(k) + r_a;
+    double *y = vec(k + 1) + r_a;
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, 0.0);  // these rows' bytes are part of the whole product's figure
+#define LZ_RANGE_CASE(G)                                                                                      \
+    case G: {                                                                                                 \
+        const int64_t chunks = (rows + (kBlock / G) - 1) / (kBlock / G);                                      \
+        const int blocks = (int)std::min<int64_t>(max_blocks, round_up(chunks, 8));                           \
+        *nparts = blocks;                                                                                     \
+        if (rp64)                                                                                             \
+            hipLaunchKernelGGL((k_spmv_vector<G, int64_t>), dim3(blocks), dim3(kBlock), 0, stream, rows,      \
+                               (const int64_t *)d_rp + r_a, d_col, d_val, x, xdot, y, parts_out);             \
+        else                                                                                                  \
+            hipLaunchKernelGGL((k_spmv_vector<G, int32_t>), dim3(blocks), dim3(kBlock), 0, stream, rows,      \
+                               (const int32_t *)d_rp + r_a, d_col, d_val, x, xdot, y, parts_out);             \
+    } break;
+    switch (group) {
+        LZ_RANGE_CASE(2)
+        LZ_RANGE_CASE(4)
+        LZ_RANGE_CASE(8)
+        LZ_RANGE_CASE(16)
+        LZ_RANGE_CASE(32)
+        default:
+            LZ_RANGE_CASE(64)
+    }
+#undef LZ_RANGE_CASE
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The product while the remote entries are still on their way: every row is computed, but only rows
+// [b_lo, b_hi) -- those that read nothing remote -- count; the others are done again by phase_spmv_end.
+int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
+    if (int rc = check_can_step()) return rc;
+    if (!slab || x_ext || spmv_kind != LANCZOS_HIP_SPMV_DICT)
+        return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary SpMV");
+    if (b_lo < 0 || b_hi > n || b_lo > b_hi) return fail("lanczos_hip_phase_spmv_begin: bad row range");
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
+    if (int rc = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi)) return rc;
+    pending_lo = b_lo;
+    pending_hi = b_hi;
+    return 0;
+}
+
+// The remote entries have arrived: the rows that read them, then the reductions as phase_spmv.
+int Engine::phase_spmv_end(double *red) {
+    if (pending_lo < 0) return fail("lanczos_hip_phase_spmv_end: no product pending");
+    int np = 0;
+    if (int rc = launch_spmv_row_range(0, pending_lo, d_partials + alpha_count, &np)) return rc;
+    alpha_count += np;
+    if (int rc = launch_spmv_row_range(pending_hi, n, d_partials + alpha_count, &np)) return rc;
+    alpha_count += np;
+    pending_lo = pending_hi = -1;
+    if (int rc = launch_finalize(d_partials, alpha_count, red)) return rc;
+    if (lazy_slab) return launch_finalize(norm_parts(k - 1), k > 0 ? norm_count : 0, red + 1);
     return 0;
 }
 
@@ -1115,6 +1179,19 @@ int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red) {
 int lanczos_hip_phase_dots(lanczos_hip_engine *e, double *red, int *n_red) {
     if (!e || !red || !n_red) return lz::fail("lanczos_hip_phase_dots: NULL argument");
     return E(e)->phase_dots(red, n_red);
+}
+int lanczos_hip_phase_spmv_begin(lanczos_hip_engine *e, int64_t first_interior_row, int64_t end_interior_row) {
+    if (!e) return lz::fail("lanczos_hip_phase_spmv_begin: NULL engine");
+    return E(e)->phase_spmv_begin(first_interior_row, end_interior_row);
+}
+int lanczos_hip_phase_spmv_end(lanczos_hip_engine *e, double *red) {
+    if (!e || !red) return lz::fail("lanczos_hip_phase_spmv_end: NULL argument");
+    return E(e)->phase_spmv_end(red);
+}
+int lanczos_hip_phase_spmv_can_overlap(const lanczos_hip_engine *e) {
+    if (!e) return 0;
+    const lz::Engine *g = E(e);
+    return g->slab && !g->x_ext && g->spmv_kind == LANCZOS_HIP_SPMV_DICT;
 }
 int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red) {
     if (!e || !red) return lz::fail("lanczos_hip_phase_recur_lazy: NULL argument");

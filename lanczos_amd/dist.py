@@ -143,6 +143,16 @@ class Comm:
     def neighbour_exchange(self, send_lo, recv_lo, send_hi, recv_hi):
         """send_lo goes to rank-1, send_hi to rank+1; recv_lo comes from rank-1, recv_hi from rank+1.
         Any of them may be None."""
+        self.neighbour_exchange_finish(self.neighbour_exchange_start(send_lo, recv_lo, send_hi, recv_hi))
+
+    def neighbour_exchange_finish(self, works):
+        """Orders the current stream behind the transfers (the host does not wait)."""
+        for r in works:
+            r.wait()
+
+    def neighbour_exchange_start(self, send_lo, recv_lo, send_hi, recv_hi):
+        """Starts the transfers behind what the current stream holds so far and returns at once;
+        kernels enqueued before neighbour_exchange_finish run beside them."""
         ops = []
         d = self.dist
         if send_lo is not None:
@@ -153,9 +163,7 @@ class Comm:
             ops.append(d.P2POp(d.isend, send_hi, self.rank + 1))
         if recv_lo is not None:
             ops.append(d.P2POp(d.irecv, recv_lo, self.rank - 1))
-        if ops:
-            for r in d.batch_isend_irecv(ops):
-                r.wait()
+        return d.batch_isend_irecv(ops) if ops else []
 
 
 class StagedComm(Comm):
@@ -183,7 +191,8 @@ class StagedComm(Comm):
         else:
             out.copy_(inp)
 
-    def neighbour_exchange(self, send_lo, recv_lo, send_hi, recv_hi):
+    def neighbour_exchange_start(self, send_lo, recv_lo, send_hi, recv_hi):
+        # host-staged: complete on return
         d = self.dist
         bufs = {}
         reqs = []
@@ -203,6 +212,7 @@ class StagedComm(Comm):
             recv_hi.copy_(bufs["hi"])
         if recv_lo is not None:
             recv_lo.copy_(bufs["lo"])
+        return []
 
 
 class DistLanczos:
@@ -215,7 +225,7 @@ class DistLanczos:
     """
 
     def __init__(self, comm: Comm, torch, device, plan: SlabPlan, bounds, max_iter: int, make_engine,
-                 reorth: str = "full"):
+                 reorth: str = "full", interior=None):
         self.comm, self.torch, self.device = comm, torch, device
         self.plan, self.bounds, self.max_iter, self.reorth = plan, bounds, max_iter, reorth
         self.rank, self.world = comm.rank, comm.world
@@ -233,6 +243,8 @@ class DistLanczos:
         else:
             self.x_ext = torch.zeros(plan.n_ext, dtype=torch.float64, device=device)
             self.engine = make_engine(plan, self.x_ext, max_iter)
+        # rows [interior[0], interior[1]) read nothing remote: their product can run beside the exchange
+        self.interior = interior if (interior and self.in_place and getattr(self.engine, "can_overlap", False)) else None
         self.k = 0
         self.reorth_steps = 0
         # no reorthogonalisation: unnormalised basis, one reduction of two doubles per iteration
@@ -267,7 +279,7 @@ class DistLanczos:
             self.tracker.reset()
 
     # -- the vector exchange --------------------------------------------------
-    def exchange(self):
+    def exchange(self, start_only=False):
         p, n = self.plan, self.plan.n_local
         if p.mode == "allgather":
             mine = self.x_ext[self.rank * self.pad: self.rank * self.pad + n]
@@ -281,18 +293,28 @@ class DistLanczos:
             x, base = self.x_ext, n
             self.engine.export_vector(self.k, x[:n])
         if self.world == 1:
-            return
+            return []
         send_lo = x[:self.send_lo] if self.send_lo else None
         send_hi = x[n - self.send_hi:n] if self.send_hi else None
         recv_lo = x[base:base + p.halo_lo] if p.halo_lo else None
         recv_hi = x[base + p.halo_lo:base + p.halo_lo + p.halo_hi] if p.halo_hi else None
-        self.comm.neighbour_exchange(send_lo, recv_lo, send_hi, recv_hi)
+        works = self.comm.neighbour_exchange_start(send_lo, recv_lo, send_hi, recv_hi)
+        if start_only:
+            return works
+        self.comm.neighbour_exchange_finish(works)
+        return []
 
     # -- one iteration (reference src/lanczos.c:109-190, split at the reductions) --
     def step(self):
         e, red = self.engine, self.red
-        self.exchange()
-        e.phase_spmv(red)
+        if self.interior:
+            works = self.exchange(start_only=True)        # the transfers run beside the product
+            e.phase_spmv_begin(*self.interior)
+            self.comm.neighbour_exchange_finish(works)
+            e.phase_spmv_end(red)
+        else:
+            self.exchange()
+            e.phase_spmv(red)
         if self.lazy:
             self.comm.all_reduce_sum(red[:2])             # u_k . A u_k and |u_k|^2 together
             e.phase_recur_lazy(red)
@@ -381,6 +403,16 @@ class _GpuPhaseEngine:
     def phase_scale(self, red):
         self.e.phase_scale(red.data_ptr())
 
+    @property
+    def can_overlap(self):
+        return self.e.can_overlap
+
+    def phase_spmv_begin(self, lo, hi):
+        self.e.phase_spmv_begin(lo, hi)
+
+    def phase_spmv_end(self, red):
+        self.e.phase_spmv_end(red.data_ptr())
+
     def phase_recur_lazy(self, red):
         self.e.phase_recur_lazy(red.data_ptr())
 
@@ -394,6 +426,25 @@ class _GpuPhaseEngine:
         return self.e.history(count)
 
 
+def interior_rows(row_head: np.ndarray, plan: SlabPlan, max_boundary_share: float = 0.25):
+    """(first, end) of the rows between those that read remote entries, when the latter are a
+    prefix (reading the previous slab) and a suffix (reading the next one) of the slab and few
+    enough to be worth computing twice; None otherwise."""
+    if plan.mode != "halo" or not plan.in_place:
+        return None
+    n = plan.n_local
+    remote = np.flatnonzero(plan.column_index >= plan.remote_base)
+    if remote.size == 0:
+        return None
+    rows = np.searchsorted(row_head, remote, side="right") - 1
+    from_lo = plan.column_index[remote] < plan.remote_base + plan.halo_lo
+    first = int(rows[from_lo].max()) + 1 if from_lo.any() else 0
+    end = int(rows[~from_lo].min()) if (~from_lo).any() else n
+    if first > end or (first + n - end) > max_boundary_share * n:
+        return None
+    return first, end
+
+
 def choose_mode(cols, bounds, rank, comm, want="auto"):
     """All ranks must use the same exchange form: halo only if every rank can."""
     if want in ("halo", "allgather"):
@@ -405,7 +456,7 @@ def choose_mode(cols, bounds, rank, comm, want="auto"):
 
 
 def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mode="auto", spmv="auto",
-                   profile=False, in_place=True):
+                   profile=False, in_place=True, overlap=True):
     """a_local: this rank's slab as a CrsMatrix with GLOBAL column indices."""
     rank = comm.rank
     device = torch.device("cuda", torch.cuda.current_device())
@@ -424,7 +475,11 @@ def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mo
     def make_engine(plan_, x_ext, max_iter_):
         return _GpuPhaseEngine(la, a_local, plan_, x_ext, max_iter_, reorth, n_global, stream, spmv, profile)
 
-    runner = DistLanczos(comm, torch, device, plan, bounds, max_iter, make_engine, reorth)
+    # every rank takes the same decision, or the collectives of the two step forms would not pair up
+    inner = interior_rows(a_local.row_head_indexes, plan) if overlap else None
+    if not comm.all_agree(inner is not None or comm.world == 1):
+        inner = None
+    runner = DistLanczos(comm, torch, device, plan, bounds, max_iter, make_engine, reorth, inner)
     runner.stream = side  # keeps the stream alive as long as the engine launches on it
     return runner
 

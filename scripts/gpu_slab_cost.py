@@ -30,8 +30,8 @@ class SilentComm(Comm):
     def all_gather_into(self, out, inp):
         pass
 
-    def neighbour_exchange(self, send_lo, recv_lo, send_hi, recv_hi):
-        pass
+    def neighbour_exchange_start(self, send_lo, recv_lo, send_hi, recv_hi):
+        return []
 
 
 def run(N, world, reorth, steps):
@@ -51,7 +51,7 @@ def run(N, world, reorth, steps):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     return {"grid": N, "world": world, "reorth": reorth, "steps": steps, "rows_per_rank": bounds[rank + 1] - bounds[rank],
-            "exchange": r.plan.mode, "ms_per_step": dt / steps * 1e3}
+            "exchange": r.plan.mode, "interior_rows": r.interior, "ms_per_step": dt / steps * 1e3}
 
 
 out = []

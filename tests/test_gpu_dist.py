@@ -135,3 +135,38 @@ def test_caller_owned_basis_is_validated(gpu):
         assert np.max(np.abs(w - want)) < 1e-14
         assert abs(float(red[0]) - float(want @ (v0 / np.linalg.norm(v0)))) < 1e-12
         assert not basis[:, 3000:].any()
+
+
+def test_split_product_matches_the_whole_one(gpu):
+    """phase_spmv_begin / phase_spmv_end (interior rows first, the rest after the exchange) against
+    phase_spmv on the same vector: same y up to the order of a row's sum, same u.Au."""
+    import torch
+    import lanczos_amd as la
+    a = la.synth_laplacian(3, 24)
+    n = a.dimension
+    base = la.gather_base(n)
+    basis = torch.zeros(3, base + 2048, dtype=torch.float64, device="cuda")
+    v0 = la.gaussian_fill(11, 0, n)
+    v0 /= np.linalg.norm(v0)
+    red = torch.zeros(16, dtype=torch.float64, device="cuda")
+    with la.Engine(a, 5, reorth="none", n_global=n, n_ext=base, basis=basis.data_ptr(), basis_ld=base + 2048) as e:
+        assert e.spmv_name.startswith("dict") and e.can_overlap
+        e.set_start_scaled(v0, 1.0)
+        e.phase_spmv(red.data_ptr())
+        torch.cuda.synchronize()
+        whole, dot = basis[1, :n].cpu().numpy().copy(), float(red[0])
+        basis[1].zero_()
+        e.phase_spmv_begin(600, n - 1000)
+        e.phase_spmv_end(red.data_ptr())
+        torch.cuda.synchronize()
+        split = basis[1, :n].cpu().numpy()
+        assert np.array_equal(split[600:n - 1000], whole[600:n - 1000])
+        assert np.max(np.abs(split - whole)) < 1e-14
+        assert abs(float(red[0]) - dot) < 1e-13 * abs(dot)
+        # an empty edge on either side
+        e.phase_spmv_begin(0, n)
+        e.phase_spmv_end(red.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(basis[1, :n].cpu().numpy(), whole) and abs(float(red[0]) - dot) < 1e-13 * abs(dot)
+        with pytest.raises(la.LanczosHipError, match="row range"):
+            e.phase_spmv_begin(10, 5)
