@@ -625,9 +625,17 @@ int Engine::phase_spmv(double *red) {
     if (int rc = check_can_step()) return rc;
     const double *x = x_ext ? x_ext : vec(k);
     if (int rc = launch_spmv(x, vec(k), vec(k + 1), &alpha_count)) return rc;
-    if (int rc = launch_finalize(d_partials, alpha_count, red)) return rc;
-    if (lazy_slab)  // the slab's part of |u_k|^2 rides along: one reduction over ranks per iteration
-        return launch_finalize(norm_parts(k - 1), k > 0 ? norm_count : 0, red + 1);
+    return finalize_spmv(red);
+}
+
+// red[0] = this slab's u_k . w; with deferred normalisation the slab's part of |u_k|^2 rides along
+// in red[1]: one reduction over ranks per iteration
+int Engine::finalize_spmv(double *red) {
+    if (!lazy_slab) return launch_finalize(d_partials, alpha_count, red);
+    ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (alpha_count + norm_count));
+    hipLaunchKernelGGL(k_finalize2, dim3(1), dim3(kBlock), 0, stream, (const double *)d_partials, alpha_count,
+                       (const double *)norm_parts(k - 1), k > 0 ? norm_count : 0, red);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -690,9 +698,7 @@ int Engine::phase_spmv_end(double *red) {
     if (int rc = launch_spmv_row_range(pending_hi, n, d_partials + alpha_count, &np)) return rc;
     alpha_count += np;
     pending_lo = pending_hi = -1;
-    if (int rc = launch_finalize(d_partials, alpha_count, red)) return rc;
-    if (lazy_slab) return launch_finalize(norm_parts(k - 1), k > 0 ? norm_count : 0, red + 1);
-    return 0;
+    return finalize_spmv(red);
 }
 
 // Recurrence with deferred normalisation on a row slab: red[0] = u_k . A u_k and red[1] = |u_k|^2,

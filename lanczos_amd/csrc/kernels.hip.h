@@ -658,6 +658,23 @@ k_finalize(const double *__restrict__ partials, int count, double *__restrict__ 
     if (threadIdx.x == 0) out[0] = t;
 }
 
+// Two sums in one launch: out[0] = sum(a[0..na)), out[1] = sum(b[0..nb)), each in a fixed order
+__global__ void __launch_bounds__(kBlock)
+k_finalize2(const double *__restrict__ a, int na, const double *__restrict__ b, int nb, double *__restrict__ out) {
+    __shared__ double red[kWavesPerBlock];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < na; i += kBlock) s += a[i];
+    const double ta = block_sum(s, red);
+    __syncthreads();
+    s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += kBlock) s += b[i];
+    const double tb = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        out[0] = ta;
+        out[1] = tb;
+    }
+}
+
 // h[l] = sum_b hpart[l * stride + b], one workgroup per l
 __global__ void __launch_bounds__(kBlock)
 k_hreduce(const double *__restrict__ hpart, int stride, int count, double *__restrict__ h) {
