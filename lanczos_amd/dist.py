@@ -460,6 +460,9 @@ def build_gpu_rank(la, torch, comm, a_local, bounds, max_iter, reorth="full", mo
     """a_local: this rank's slab as a CrsMatrix with GLOBAL column indices."""
     rank = comm.rank
     device = torch.device("cuda", torch.cuda.current_device())
+    # switches for comparing the exchange forms on a real node (same value on every rank)
+    in_place = in_place and os.environ.get("LANCZOS_DIST_NO_INPLACE", "0") != "1"
+    overlap = overlap and os.environ.get("LANCZOS_DIST_NO_OVERLAP", "0") != "1"
     mode = choose_mode(a_local.column_index, bounds, rank, comm, mode)
     n_local = bounds[rank + 1] - bounds[rank]
     plan = plan_slab(a_local.column_index, bounds, rank, mode, la.gather_base(n_local) if in_place else -1)
@@ -576,6 +579,8 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                             f"({runner.plan.mode} exchange + {1 if runner.lazy else 2} all-reduce(s) per step)",
                 "reorth": args.reorth,
                 "exchange": runner.plan.mode,
+                "exchange_in_place": bool(runner.in_place),
+                "exchange_overlapped_with_product": runner.interior is not None,
                 "parallelism": f"row-partition x{world}",
             },
             "roofline": {
@@ -610,6 +615,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
             "exchange": r2.plan.mode,
             "all_reduces_per_step": 1 if r2.lazy else 2,
+            "exchange_overlapped_with_product": r2.interior is not None,
         }
     del r2
     torch.cuda.empty_cache()
@@ -668,6 +674,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                 "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt4 / 1e9,
                 "spmv_avg_ms_rank0": p4["spmv"]["ms"] / steps2,
                 "exchange": r4.plan.mode,
+                "exchange_overlapped_with_product": r4.interior is not None,
             }
         del r4
     dist.barrier()
