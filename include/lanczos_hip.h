@@ -366,12 +366,12 @@ int lanczos_hip_phase_scale(lanczos_hip_engine *e, double *red);
 int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red);
 /*
  * lanczos_hip_phase_spmv in two parts, so that the exchange of the remote entries runs while the
- * product does (engines with options.basis whose matrix took the dictionary SpMV:
- * lanczos_hip_phase_spmv_can_overlap).  Rows [first_interior_row, end_interior_row) are the ones
+ * product does (engines with options.basis whose matrix took the dictionary, rows, stream or
+ * vector SpMV: lanczos_hip_phase_spmv_can_overlap).  Rows [first_interior_row, end_interior_row) are the ones
  * that read no remote entry.
  *   lanczos_hip_phase_spmv_begin  may be enqueued while the tail of vector k is still being
- *                                 received: w = A x for every row, but only the interior rows
- *                                 count towards u_k . w
+ *                                 received: w = A x and u_k . w for the interior rows (the
+ *                                 dictionary form computes every row, the others not counting)
  *   lanczos_hip_phase_spmv_end    once the receives are ordered before it on the stream: the
  *                                 other rows again (plain row-wise kernel, src/crs.c:167-177),
  *                                 then red[] as lanczos_hip_phase_spmv leaves it

@@ -135,6 +135,7 @@ struct Engine {
     int phase_scale(double *red);
     int phase_spmv_begin(int64_t b_lo, int64_t b_hi);
     int phase_spmv_end(double *red);
+    bool can_split_product() const;
     int finalize_spmv(double *red);
     int launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, int *nparts);
     int64_t pending_lo = -1, pending_hi = -1;  // rows [0, lo) and [hi, n) wait for phase_spmv_end

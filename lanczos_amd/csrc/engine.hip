@@ -427,9 +427,15 @@ double Engine::spmv_bytes() const {
     return 12.0 * (double)nnz + (rp64 ? 8.0 : 4.0) * (double)(n + 1) + 8.0 * (double)n_ext + 8.0 * (double)n;
 }
 
+// Rows [r_a, r_a + rows) of the product: the row offsets, y and xdot shifted, x and the entry arrays as
+// they are (column indices are absolute).  The merge and pipe forms hold precomputed splits of the
+// whole matrix and only take r_a = 0, rows = n.
 template <typename RP>
-static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double *y, int *nparts) {
-    const RP *rp = (const RP *)e->d_rp;
+static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, double *y_all, int *nparts,
+                          int64_t r_a, int64_t rows, double *parts) {
+    const RP *rp = (const RP *)e->d_rp + r_a;
+    const double *xdot = xdot_all + r_a;
+    double *y = y_all + r_a;
     if (e->spmv_kind == LANCZOS_HIP_SPMV_MERGE) {
         const int64_t tiles = (e->nnz + kTile - 1) / kTile;
         const int fix = 64;
@@ -443,12 +449,12 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double
         return;
     }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_ROWS) {
-        const int64_t groups = (e->n + 63) / 64;
+        const int64_t groups = (rows + 63) / 64;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
         int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
         *nparts = blocks;
-        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp, e->d_col,
-                           e->d_val, x, xdot, y, e->d_partials);
+        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, rp, e->d_col,
+                           e->d_val, x, xdot, y, parts);
         return;
     }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_PIPE || e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {
@@ -480,21 +486,21 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot, double
         return;
     }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_STREAM) {
-        const int64_t groups = (e->n + 63) / 64;
+        const int64_t groups = (rows + 63) / 64;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
         int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
         *nparts = blocks;
-        hipLaunchKernelGGL((k_spmv_stream<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp, e->d_col,
-                           e->d_val, x, xdot, y, e->d_partials);
+        hipLaunchKernelGGL((k_spmv_stream<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, rp, e->d_col,
+                           e->d_val, x, xdot, y, parts);
         return;
     }
 #define LZ_VEC_CASE(G)                                                                                        \
     case G: {                                                                                                 \
-        const int64_t chunks = (e->n + (kBlock / G) - 1) / (kBlock / G);                                      \
+        const int64_t chunks = (rows + (kBlock / G) - 1) / (kBlock / G);                                      \
         int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));                              \
         *nparts = blocks;                                                                                     \
-        hipLaunchKernelGGL((k_spmv_vector<G, RP>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n, rp,       \
-                           e->d_col, e->d_val, x, xdot, y, e->d_partials);                                    \
+        hipLaunchKernelGGL((k_spmv_vector<G, RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, rp,       \
+                           e->d_col, e->d_val, x, xdot, y, parts);                                            \
     } break;
     switch (e->group) {
         LZ_VEC_CASE(2)
@@ -519,9 +525,9 @@ int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *npa
     if (spmv_kind == LANCZOS_HIP_SPMV_DICT) return launch_spmv_dict(x, xdot, y, nparts);
     if (spmv_kind == LANCZOS_HIP_SPMV_PANEL) return launch_spmv_panels(x, xdot, y, nparts);
     if (rp64)
-        launch_spmv_t<int64_t>(this, x, xdot, y, nparts);
+        launch_spmv_t<int64_t>(this, x, xdot, y, nparts, 0, n, d_partials);
     else
-        launch_spmv_t<int32_t>(this, x, xdot, y, nparts);
+        launch_spmv_t<int32_t>(this, x, xdot, y, nparts, 0, n, d_partials);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -679,14 +685,35 @@ int Engine::launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, i
 // [b_lo, b_hi) -- those that read nothing remote -- count; the others are done again by phase_spmv_end.
 int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
     if (int rc = check_can_step()) return rc;
-    if (!slab || x_ext || spmv_kind != LANCZOS_HIP_SPMV_DICT)
-        return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary SpMV");
+    if (!can_split_product())
+        return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary, rows, stream or "
+                    "vector SpMV");
     if (b_lo < 0 || b_hi > n || b_lo > b_hi) return fail("lanczos_hip_phase_spmv_begin: bad row range");
     ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
-    if (int rc = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi)) return rc;
+    if (spmv_kind == LANCZOS_HIP_SPMV_DICT) {
+        // every row at once; the edge rows are done again later and do not count towards the dot product
+        if (int rc = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi)) return rc;
+    } else {
+        // the interior rows alone, from a multiple of 64 (the rows form's 64-row groups were sized on those)
+        b_lo = std::min(round_up(b_lo, 64), b_hi);
+        alpha_count = 0;
+        if (b_hi > b_lo) {
+            if (rp64)
+                launch_spmv_t<int64_t>(this, vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi - b_lo, d_partials);
+            else
+                launch_spmv_t<int32_t>(this, vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi - b_lo, d_partials);
+            HIP_TRY(hipGetLastError());
+        }
+    }
     pending_lo = b_lo;
     pending_hi = b_hi;
     return 0;
+}
+
+bool Engine::can_split_product() const {
+    return slab && !x_ext && nnz > 0 &&
+           (spmv_kind == LANCZOS_HIP_SPMV_DICT || spmv_kind == LANCZOS_HIP_SPMV_ROWS ||
+            spmv_kind == LANCZOS_HIP_SPMV_STREAM || spmv_kind == LANCZOS_HIP_SPMV_VECTOR);
 }
 
 // The remote entries have arrived: the rows that read them, then the reductions as phase_spmv.
@@ -1196,8 +1223,7 @@ int lanczos_hip_phase_spmv_end(lanczos_hip_engine *e, double *red) {
 }
 int lanczos_hip_phase_spmv_can_overlap(const lanczos_hip_engine *e) {
     if (!e) return 0;
-    const lz::Engine *g = E(e);
-    return g->slab && !g->x_ext && g->spmv_kind == LANCZOS_HIP_SPMV_DICT;
+    return E(e)->can_split_product();
 }
 int lanczos_hip_phase_recur_lazy(lanczos_hip_engine *e, double *red) {
     if (!e || !red) return lz::fail("lanczos_hip_phase_recur_lazy: NULL argument");

@@ -137,7 +137,8 @@ def test_caller_owned_basis_is_validated(gpu):
         assert not basis[:, 3000:].any()
 
 
-def test_split_product_matches_the_whole_one(gpu):
+@pytest.mark.parametrize("kind", ["auto", "rows", "stream", "vector"])
+def test_split_product_matches_the_whole_one(gpu, kind):
     """phase_spmv_begin / phase_spmv_end (interior rows first, the rest after the exchange) against
     phase_spmv on the same vector: same y up to the order of a row's sum, same u.Au."""
     import torch
@@ -149,8 +150,9 @@ def test_split_product_matches_the_whole_one(gpu):
     v0 = la.gaussian_fill(11, 0, n)
     v0 /= np.linalg.norm(v0)
     red = torch.zeros(16, dtype=torch.float64, device="cuda")
-    with la.Engine(a, 5, reorth="none", n_global=n, n_ext=base, basis=basis.data_ptr(), basis_ld=base + 2048) as e:
-        assert e.spmv_name.startswith("dict") and e.can_overlap
+    with la.Engine(a, 5, reorth="none", spmv=kind, n_global=n, n_ext=base, basis=basis.data_ptr(),
+                   basis_ld=base + 2048) as e:
+        assert e.spmv_name.startswith("dict" if kind == "auto" else kind) and e.can_overlap
         e.set_start_scaled(v0, 1.0)
         e.phase_spmv(red.data_ptr())
         torch.cuda.synchronize()
@@ -160,7 +162,7 @@ def test_split_product_matches_the_whole_one(gpu):
         e.phase_spmv_end(red.data_ptr())
         torch.cuda.synchronize()
         split = basis[1, :n].cpu().numpy()
-        assert np.array_equal(split[600:n - 1000], whole[600:n - 1000])
+        assert np.array_equal(split[640:n - 1000], whole[640:n - 1000])
         assert np.max(np.abs(split - whole)) < 1e-14
         assert abs(float(red[0]) - dot) < 1e-13 * abs(dot)
         # an empty edge on either side
@@ -168,5 +170,10 @@ def test_split_product_matches_the_whole_one(gpu):
         e.phase_spmv_end(red.data_ptr())
         torch.cuda.synchronize()
         assert np.array_equal(basis[1, :n].cpu().numpy(), whole) and abs(float(red[0]) - dot) < 1e-13 * abs(dot)
+        # no interior at all: every row through the edge kernel
+        e.phase_spmv_begin(700, 700)
+        e.phase_spmv_end(red.data_ptr())
+        torch.cuda.synchronize()
+        assert np.max(np.abs(basis[1, :n].cpu().numpy() - whole)) < 1e-14 and abs(float(red[0]) - dot) < 1e-13 * abs(dot)
         with pytest.raises(la.LanczosHipError, match="row range"):
             e.phase_spmv_begin(10, 5)
