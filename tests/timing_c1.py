@@ -2,7 +2,7 @@
 import sys
 import time
 
-sys.path.insert(0, ".")
+sys.path.insert(0, ".")  # run from the repository root: python tests/timing_c1.py
 import lanczos_amd as la
 import oracle
 
