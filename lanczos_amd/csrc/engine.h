@@ -137,7 +137,7 @@ struct Engine {
     int phase_spmv_end(double *red);
     bool can_split_product() const;
     int finalize_spmv(double *red);
-    int launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, int *nparts);
+    int launch_spmv_edges(int64_t lo, int64_t hi, double *parts_out, int *nparts);
     int64_t pending_lo = -1, pending_hi = -1;  // rows [0, lo) and [hi, n) wait for phase_spmv_end
     int phase_recur_lazy(double *red);
     int phase_lazy_norm(double *red);

@@ -348,7 +348,7 @@ int Engine::alloc_state() {
     HIP_TRY(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)ldv * (size_t)nvec, stream));
 
     // ---- small buffers
-    HIP_TRY(hipMalloc(&d_partials, sizeof(double) * 3 * max_blocks));  // one SpMV, or one plus two row ranges
+    HIP_TRY(hipMalloc(&d_partials, sizeof(double) * 2 * max_blocks));  // one SpMV, or one plus the edge rows
     HIP_TRY(hipMalloc(&d_norm_parts, sizeof(double) * 2 * max_blocks));
     HIP_TRY(hipMemsetAsync(d_norm_parts, 0, sizeof(double) * 2 * max_blocks, stream));
     lazy = (reorth == LANCZOS_HIP_REORTH_NONE || reorth == LANCZOS_HIP_REORTH_SELECTIVE) && !slab;
@@ -645,38 +645,37 @@ int Engine::finalize_spmv(double *red) {
     return 0;
 }
 
-// Rows [r_a, r_b) of the product through the plain row-wise kernel (src/crs.c:167-177): the same
-// arrays with the row offsets, y and xdot shifted; parts_out receives the partials of xdot . y.
-int Engine::launch_spmv_row_range(int64_t r_a, int64_t r_b, double *parts_out, int *nparts) {
+// Rows [0, lo) and [hi, n) of the product through the plain row-wise form (src/crs.c:167-177), one
+// launch; parts_out receives the partials of xdot . y.
+int Engine::launch_spmv_edges(int64_t lo, int64_t hi, double *parts_out, int *nparts) {
     *nparts = 0;
-    const int64_t rows = r_b - r_a;
-    if (rows <= 0) return 0;
+    const int64_t m = lo + (n - hi);
+    if (m <= 0) return 0;
     const double *x = vec(k);
-    const double *xdot = vec(k) + r_a;
-    double *y = vec(k + 1) + r_a;
+    double *y = vec(k + 1);
     ProfScope ps(this, LANCZOS_HIP_K_SPMV, 0.0);  // these rows' bytes are part of the whole product's figure
-#define LZ_RANGE_CASE(G)                                                                                      \
+#define LZ_EDGE_CASE(G)                                                                                       \
     case G: {                                                                                                 \
-        const int64_t chunks = (rows + (kBlock / G) - 1) / (kBlock / G);                                      \
-        const int blocks = (int)std::min<int64_t>(max_blocks, round_up(chunks, 8));                           \
+        const int64_t chunks = (m + (kBlock / G) - 1) / (kBlock / G);                                         \
+        const int blocks = (int)std::min<int64_t>(max_blocks, chunks);                                        \
         *nparts = blocks;                                                                                     \
         if (rp64)                                                                                             \
-            hipLaunchKernelGGL((k_spmv_vector<G, int64_t>), dim3(blocks), dim3(kBlock), 0, stream, rows,      \
-                               (const int64_t *)d_rp + r_a, d_col, d_val, x, xdot, y, parts_out);             \
+            hipLaunchKernelGGL((k_spmv_edges<G, int64_t>), dim3(blocks), dim3(kBlock), 0, stream, lo, hi, n,  \
+                               (const int64_t *)d_rp, d_col, d_val, x, x, y, parts_out);                      \
         else                                                                                                  \
-            hipLaunchKernelGGL((k_spmv_vector<G, int32_t>), dim3(blocks), dim3(kBlock), 0, stream, rows,      \
-                               (const int32_t *)d_rp + r_a, d_col, d_val, x, xdot, y, parts_out);             \
+            hipLaunchKernelGGL((k_spmv_edges<G, int32_t>), dim3(blocks), dim3(kBlock), 0, stream, lo, hi, n,  \
+                               (const int32_t *)d_rp, d_col, d_val, x, x, y, parts_out);                      \
     } break;
     switch (group) {
-        LZ_RANGE_CASE(2)
-        LZ_RANGE_CASE(4)
-        LZ_RANGE_CASE(8)
-        LZ_RANGE_CASE(16)
-        LZ_RANGE_CASE(32)
+        LZ_EDGE_CASE(2)
+        LZ_EDGE_CASE(4)
+        LZ_EDGE_CASE(8)
+        LZ_EDGE_CASE(16)
+        LZ_EDGE_CASE(32)
         default:
-            LZ_RANGE_CASE(64)
+            LZ_EDGE_CASE(64)
     }
-#undef LZ_RANGE_CASE
+#undef LZ_EDGE_CASE
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -720,9 +719,7 @@ bool Engine::can_split_product() const {
 int Engine::phase_spmv_end(double *red) {
     if (pending_lo < 0) return fail("lanczos_hip_phase_spmv_end: no product pending");
     int np = 0;
-    if (int rc = launch_spmv_row_range(0, pending_lo, d_partials + alpha_count, &np)) return rc;
-    alpha_count += np;
-    if (int rc = launch_spmv_row_range(pending_hi, n, d_partials + alpha_count, &np)) return rc;
+    if (int rc = launch_spmv_edges(pending_lo, pending_hi, d_partials + alpha_count, &np)) return rc;
     alpha_count += np;
     pending_lo = pending_hi = -1;
     return finalize_spmv(red);

@@ -153,6 +153,37 @@ k_spmv_vector(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ 
     if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
 }
 
+// The same for the two edge ranges of a row slab in one launch: rows [0, lo) and [hi, n), the rows
+// that read entries received from the neighbouring slabs (m = lo + n - hi rows in all).
+template <int G, typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_edges(int64_t lo, int64_t hi, int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+             const double *__restrict__ val, const double *__restrict__ x, const double *__restrict__ xdot,
+             double *__restrict__ y, double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    constexpr int RPB = kBlock / G;
+    const int g_lane = threadIdx.x & (G - 1);
+    const int g_id = threadIdx.x / G;
+    const int64_t m = lo + (n - hi);
+    double acc = 0.0;
+    for (int64_t c = blockIdx.x; c * RPB < m; c += gridDim.x) {
+        const int64_t e = c * RPB + g_id;
+        const int64_t row = e < lo ? e : e - lo + hi;
+        double sum = 0.0;
+        if (e < m) {
+            const RP s = rp[row], t = rp[row + 1];
+            for (RP j = s + g_lane; j < t; j += G) sum += val[j] * x[col[j]];
+        }
+        sum = group_sum<G>(sum);
+        if (g_lane == 0 && e < m) {
+            y[row] = sum;
+            acc += sum * xdot[row];
+        }
+    }
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
 // ---------------------------------------------------------------------------
 // SpMV, "stream" form: one wavefront per group of 64 rows
 // ---------------------------------------------------------------------------
