@@ -21,6 +21,15 @@ void parse_to_coo(char *src_line, Coo *dist);
 /* Two-pass reader: '\n'-separated lines, zero-length lines skipped,
  * dimension = largest index + 1 (src/coo.c:101-269). */
 Mat_Coo read_mat_coo_incremental(const char *filepath);
+/*
+ * Matrix Market coordinate files (real / integer / pattern; general / symmetric / skew-symmetric,
+ * the stored triangle mirrored).  An extension: the reference's reader takes the banner for a
+ * malformed index and exits (src/coo.c:19-22).  Returns EXIT_SUCCESS and a malloc'd Mat_Coo, or
+ * EXIT_FAILURE with a message on stderr.  is_matrix_market() tells whether a file starts with the
+ * banner.
+ */
+int read_matrix_market(const char *filepath, Mat_Coo *out);
+int is_matrix_market(const char *filepath);
 /* dist = A vec by scatter-add in entry order (src/coo.c:271-283). */
 void matvec_coo(const Mat_Coo *mat, const double vec[], double *dist);
 

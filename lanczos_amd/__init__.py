@@ -141,6 +141,10 @@ _hip.lanczos_hip_local_vector.restype = C.c_void_p
 _hip.lanczos_hip_history.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
 _hip.lanczos_hip_history.restype = C.c_int
 
+_host.read_matrix_market.argtypes = [C.c_char_p, C.POINTER(Mat_Coo)]
+_host.read_matrix_market.restype = C.c_int
+_host.is_matrix_market.argtypes = [C.c_char_p]
+_host.is_matrix_market.restype = C.c_int
 _host.read_mat_coo_incremental.argtypes = [C.c_char_p]
 _host.read_mat_coo_incremental.restype = Mat_Coo
 _host.parse_to_coo.argtypes = [C.c_char_p, C.POINTER(Coo)]
@@ -214,6 +218,24 @@ def read_mat_coo_incremental(path: str):
         C.memmove(arr.ctypes.data, m.data, n * COO_DTYPE.itemsize)
         _libc.free(C.cast(m.data, C.c_void_p))
     return arr, int(m.dimension)
+
+
+def read_matrix_market(path: str):
+    """Matrix Market coordinate file -> (structured array of Coo, dimension); symmetric and
+    skew-symmetric files come back with both triangles.  Raises on unsupported or malformed files."""
+    m = Mat_Coo(None, 0, 0)
+    if _host.read_matrix_market(os.fsencode(path), C.byref(m)) != 0:
+        raise ValueError(f"read_matrix_market: cannot read {path} (see stderr)")
+    n = int(m.length)
+    arr = np.zeros(n, COO_DTYPE)
+    if n:
+        C.memmove(arr.ctypes.data, m.data, n * COO_DTYPE.itemsize)
+    _libc.free(C.cast(m.data, C.c_void_p))
+    return arr, int(m.dimension)
+
+
+def is_matrix_market(path: str) -> bool:
+    return bool(_host.is_matrix_market(os.fsencode(path)))
 
 
 def parse_to_coo(line: str):

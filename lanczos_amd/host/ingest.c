@@ -136,6 +136,152 @@ Mat_Coo read_mat_coo_incremental(const char *filepath) {
     return m;
 }
 
+/*
+ * Matrix Market coordinate files.  No counterpart in the reference, whose reader takes a
+ * "%%MatrixMarket" banner for a malformed index and exits (src/coo.c:19-22) and would read the size
+ * line as an entry.  Banner "%%MatrixMarket matrix coordinate <real|integer|pattern>
+ * <general|symmetric|skew-symmetric>", '%' comment lines, the size line "M N NNZ", then NNZ lines
+ * "row col [value]" (1-based).  Symmetric and skew-symmetric files hold one triangle: the mirror
+ * entries are appended after the stored ones.  Pattern entries get the value 1.
+ */
+typedef struct {
+    int phase;           /* 0 banner, 1 size line, 2 entries */
+    int pattern, mirror; /* mirror: 0 none, 1 symmetric, -1 skew-symmetric */
+    long rows, cols, declared, seen;
+    Coo *data;
+    size_t count;
+    int error;
+} mm_t;
+
+static void mm_lower(char *s) {
+    for (; *s; ++s) *s = (char)tolower((unsigned char)*s);
+}
+
+static void mm_line(char *line, void *ctx) {
+    mm_t *m = (mm_t *)ctx;
+    if (m->error) return;
+    if (m->phase == 0) {
+        char banner[64] = "", object[64] = "", format[64] = "", field[64] = "", symmetry[64] = "";
+        if (sscanf(line, "%63s %63s %63s %63s %63s", banner, object, format, field, symmetry) != 5 ||
+            strcmp(banner, "%%MatrixMarket") != 0) {
+            fprintf(stderr, "read_matrix_market: no %%%%MatrixMarket banner\n");
+            m->error = 1;
+            return;
+        }
+        mm_lower(object), mm_lower(format), mm_lower(field), mm_lower(symmetry);
+        if (strcmp(object, "matrix") || strcmp(format, "coordinate")) {
+            fprintf(stderr, "read_matrix_market: only 'matrix coordinate' files are supported (got %s %s)\n", object, format);
+            m->error = 1;
+            return;
+        }
+        if (!strcmp(field, "pattern")) m->pattern = 1;
+        else if (strcmp(field, "real") && strcmp(field, "integer")) {
+            fprintf(stderr, "read_matrix_market: field '%s' is not supported (real, integer, pattern)\n", field);
+            m->error = 1;
+            return;
+        }
+        if (!strcmp(symmetry, "symmetric")) m->mirror = 1;
+        else if (!strcmp(symmetry, "skew-symmetric")) m->mirror = -1;
+        else if (strcmp(symmetry, "general")) {
+            fprintf(stderr, "read_matrix_market: symmetry '%s' is not supported\n", symmetry);
+            m->error = 1;
+            return;
+        }
+        m->phase = 1;
+        return;
+    }
+    const char *p = skip_blank(line);
+    if (*p == '%' || *p == '\0') return; /* comment or blank line */
+    if (m->phase == 1) {
+        if (sscanf(p, "%ld %ld %ld", &m->rows, &m->cols, &m->declared) != 3 || m->rows < 1 || m->cols < 1 ||
+            m->declared < 0 || m->rows > INT32_MAX || m->cols > INT32_MAX) {
+            fprintf(stderr, "read_matrix_market: bad size line '%s'\n", p);
+            m->error = 1;
+            return;
+        }
+        const size_t cap = (size_t)m->declared * (m->mirror ? 2 : 1);
+        m->data = (Coo *)malloc(sizeof(Coo) * (cap ? cap : 1));
+        if (!m->data) {
+            fprintf(stderr, "read_matrix_market: malloc failed\n");
+            m->error = 1;
+            return;
+        }
+        m->phase = 2;
+        return;
+    }
+    long r = 0, c = 0;
+    double v = 1.0;
+    const int got = m->pattern ? sscanf(p, "%ld %ld", &r, &c) : sscanf(p, "%ld %ld %lg", &r, &c, &v);
+    if (got != (m->pattern ? 2 : 3) || r < 1 || c < 1 || r > m->rows || c > m->cols) {
+        fprintf(stderr, "read_matrix_market: bad entry '%s'\n", p);
+        m->error = 1;
+        return;
+    }
+    if (m->seen >= m->declared) {
+        fprintf(stderr, "read_matrix_market: more entries than the size line declares (%ld)\n", m->declared);
+        m->error = 1;
+        return;
+    }
+    m->seen++;
+    Coo *e = &m->data[m->count++];
+    e->index_row = (int)(r - 1);
+    e->index_column = (int)(c - 1);
+    e->value = v;
+}
+
+int read_matrix_market(const char *filepath, Mat_Coo *out) {
+    if (!filepath || !out) {
+        fprintf(stderr, "read_matrix_market: NULL argument\n");
+        return EXIT_FAILURE;
+    }
+    FILE *probe = fopen(filepath, "r");
+    if (!probe) {
+        perror("fopen");
+        return EXIT_FAILURE;
+    }
+    fclose(probe);
+    mm_t m;
+    memset(&m, 0, sizeof m);
+    for_each_line(filepath, mm_line, &m);
+    if (!m.error && m.phase != 2) {
+        fprintf(stderr, "read_matrix_market: file ends before the size line\n");
+        m.error = 1;
+    }
+    if (!m.error && m.seen != m.declared) {
+        fprintf(stderr, "read_matrix_market: %ld entries declared, %ld found\n", m.declared, m.seen);
+        m.error = 1;
+    }
+    if (m.error) {
+        free(m.data);
+        return EXIT_FAILURE;
+    }
+    if (m.mirror) { /* the other triangle, in file order, behind the stored entries */
+        const size_t stored = m.count;
+        for (size_t i = 0; i < stored; i++) {
+            const Coo e = m.data[i];
+            if (e.index_row == e.index_column) continue;
+            Coo *t = &m.data[m.count++];
+            t->index_row = e.index_column;
+            t->index_column = e.index_row;
+            t->value = m.mirror > 0 ? e.value : -e.value;
+        }
+    }
+    out->data = m.data;
+    out->length = m.count;
+    out->dimension = (size_t)(m.rows > m.cols ? m.rows : m.cols);
+    return EXIT_SUCCESS;
+}
+
+/* 1 when the file starts with the Matrix Market banner, 0 when not (or unreadable). */
+int is_matrix_market(const char *filepath) {
+    FILE *fp = filepath ? fopen(filepath, "r") : NULL;
+    if (!fp) return 0;
+    char head[16] = "";
+    const size_t n = fread(head, 1, 14, fp);
+    fclose(fp);
+    return n == 14 && memcmp(head, "%%MatrixMarket", 14) == 0;
+}
+
 /* src/coo.c:271-283 */
 void matvec_coo(const Mat_Coo *mat, const double vec[], double *dist) {
     if (!mat || !vec || !dist) {

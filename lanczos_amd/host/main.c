@@ -46,7 +46,15 @@ int main(int argc, const char *argv[]) {
         fprintf(stderr, "number_of_eigenvalues must be <= %d\n", buf_size);
         return EXIT_FAILURE;
     }
-    MEASURE(read_mat, mat = read_mat_coo_incremental(argv[1]););
+    /* a file with the Matrix Market banner goes through that reader (the reference would exit on it,
+     * src/coo.c:19-22); anything else is the reference's headerless triplet format */
+    if (is_matrix_market(argv[1])) {
+        int rc = 0;
+        MEASURE(read_mat, rc = read_matrix_market(argv[1], &mat););
+        if (rc != EXIT_SUCCESS) return EXIT_FAILURE;
+    } else {
+        MEASURE(read_mat, mat = read_mat_coo_incremental(argv[1]););
+    }
     printf("mat dim: %ld\n", (long)mat.dimension);
     printf("mat num-of-non-zero: %ld\n", (long)mat.length);
     printf("sparsity: %f\n", ((double)mat.length / ((double)mat.dimension * (double)mat.dimension)));

@@ -621,3 +621,25 @@ def test_driver_binary_on_triplet_file(gpu, tmp_path):
         eig = [float(ln.split("\t")[-1]) for ln in p.stdout.splitlines() if ln.startswith("eigenvalue")]
         assert len(eig) == 4
         assert np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12   # printed at %.12f
+
+
+def test_driver_binary_on_matrix_market_file(gpu, tmp_path):
+    """The same matrix as a symmetric Matrix Market file (one triangle stored): the driver sees the
+    banner, mirrors the triangle and arrives at the same eigenvalues as from the triplet file."""
+    n = 10000
+    r, c, v = laplacian_triplets_rowwise(n)
+    keep = r >= c
+    path = tmp_path / "lap1d.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% 1-D Laplacian, lower triangle\n")
+        f.write(f"{n} {n} {int(keep.sum())}\n")
+        f.write("".join(f"{i + 1} {j + 1} {x:g}\n" for i, j, x in zip(r[keep], c[keep], v[keep])))
+    exe = os.path.join(ROOT, "lanczos_amd", "bin", "lanczos_main")
+    a = la.synth_laplacian(1, n)
+    v0 = la.gaussian_fill(123456789, 0, n)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 101, 10e-5)
+    p = subprocess.run([exe, str(path), "crs_hip", "4", "101"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert f"mat dim: {n}" in p.stdout and f"mat num-of-non-zero: {r.size}" in p.stdout
+    eig = [float(ln.split("\t")[-1]) for ln in p.stdout.splitlines() if ln.startswith("eigenvalue")]
+    assert len(eig) == 4 and np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12

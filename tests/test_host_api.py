@@ -244,3 +244,48 @@ def test_block_model_reaches_the_closed_form_spectrum():
     assert np.max(np.abs(v.T @ av - t)) < 1e-11
     assert np.max(np.abs(bl.ritz(ab, bb, 22, 3) - laplacian_eigs(2, 20, 3))) < 1e-9
     assert np.max(np.abs(la.sym_lowest_eigs(t, 5) - np.linalg.eigvalsh(t)[:5])) < 1e-13
+
+
+def test_matrix_market_reader_against_scipy(tmp_path):
+    """The Matrix Market extension of the host library: general / symmetric / skew-symmetric / pattern
+    files with comments and blank lines, against scipy.io.mmread; malformed files are refused."""
+    import scipy.io
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(5)
+    n = 37
+    dense = sp.random(n, n, density=0.15, random_state=7, format="coo")
+    sym = (dense + dense.T).tocoo()
+    skew = (sp.triu(dense, 1) - sp.triu(dense, 1).T).tocoo()
+    cases = {"general": (dense, {}), "symmetric": (sym, {"symmetry": "symmetric"}),
+             "skew": (skew, {"symmetry": "skew-symmetric"}),
+             "pattern": (sym, {"field": "pattern", "symmetry": "symmetric"}),
+             "integer": (sp.coo_matrix(np.triu(rng.integers(-3, 4, (n, n)))), {"field": "integer"})}
+    for name, (m, kw) in cases.items():
+        path = str(tmp_path / f"{name}.mtx")
+        scipy.io.mmwrite(path, m, comment="written by the test\nsecond comment line", **kw)
+        text = open(path).read().replace("\n", "\n\n", 3)       # blank lines must not matter
+        open(path, "w").write(text)
+        assert la.is_matrix_market(path)
+        coo, dim = la.read_matrix_market(path)
+        want = scipy.io.mmread(path).toarray()
+        got = np.zeros((dim, dim))
+        np.add.at(got, (coo["index_row"], coo["index_column"]), coo["value"])
+        assert dim == n and np.array_equal(got, want), name
+        # and on through the bit-exact builder to the product
+        crs = la.convert_from_coo(coo, dim, 0)
+        x = rng.standard_normal(n)
+        assert np.allclose(la.matvec_crs(crs, x), want @ x, rtol=0, atol=1e-13)
+    plain = str(tmp_path / "plain.txt")
+    open(plain, "w").write("1 1 2.0\n1 2 -1.0\n2 1 -1.0\n2 2 2.0\n")
+    assert not la.is_matrix_market(plain)
+    for bad in ("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n",
+                "%%MatrixMarket matrix coordinate complex general\n2 2 1\n1 1 1 0\n",
+                "%%MatrixMarket matrix coordinate real general\n2 2 2\n1 1 1.0\n",
+                "%%MatrixMarket matrix coordinate real general\n2 2 1\n3 1 1.0\n",
+                "%%MatrixMarket matrix coordinate real general\n2 2 1\n1 1 1.0\n2 2 1.0\n",
+                "%%MatrixMarket matrix coordinate real general\n"):
+        path = str(tmp_path / "bad.mtx")
+        open(path, "w").write(bad)
+        with pytest.raises(ValueError):
+            la.read_matrix_market(path)
