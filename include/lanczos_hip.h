@@ -63,7 +63,9 @@ typedef struct crs {
  *                 values of the last tridiagonal matrix, ascending, entries
  *                 beyond its dimension zero (src/util.c:269-271)
  *   eigenvectors  accepted and ignored, as in both reference solvers
- *                 (src/lanczos.c:20, src/lanczos_cuda.c:284)
+ *                 (src/lanczos.c:20, src/lanczos_cuda.c:284), unless
+ *                 LANCZOS_HIP_EIGENVECTORS=1: then eigenvectors[i], i < nth_eig, when not NULL,
+ *                 receives the Ritz vector of eigenvalues[i] (dimension doubles, unit norm)
  *   max_iter      basis size; the loop runs max_iter - 1 iterations
  *                 (src/lanczos.c:104)
  *   threshold     convergence threshold of src/lanczos.c:123, 185
@@ -84,6 +86,8 @@ typedef struct crs {
  *   LANCZOS_HIP_WINDOW  iterations enqueued ahead of the one the host is looking at (default 4)
  *   LANCZOS_HIP_PROFILE 0 drops the per-kernel events behind the [TOTAL] lines (default 1)
  *   LANCZOS_HIP_JSON    1 adds one JSON line with the same split to stderr
+ *   LANCZOS_HIP_EIGENVECTORS 1 fills the eigenvectors argument (off by default: the reference's
+ *                       driver hands in an uninitialised pointer array, src/main.c:20)
  * and, read by every engine at creation:
  *   LANCZOS_HIP_NO_DICT    1 keeps the CRS kernels on matrices whose rows repeat
  *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 18)

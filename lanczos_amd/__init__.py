@@ -307,12 +307,27 @@ def tridiag_eigvecs(alpha, beta, n: int, eig) -> np.ndarray:
 
 
 # ---- solver entry points ----------------------------------------------------
-def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float) -> tuple[int, np.ndarray]:
-    """The drop-in entry; returns (status, eigenvalues[nth_eig])."""
+def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float, vectors: bool = False):
+    """The drop-in entry; returns (status, eigenvalues[nth_eig]), and with vectors=True also the
+    (nth_eig, n) array the `eigenvectors` argument was filled into (LANCZOS_HIP_EIGENVECTORS=1 for
+    the duration of the call)."""
     eig = np.zeros(max(nth_eig, 1))
     s = a.as_struct()
-    rc = _hip.lanczos_hip_crs(C.byref(s), eig.ctypes.data_as(_dp), None, nth_eig, max_iter, threshold)
-    return rc, eig[:max(nth_eig, 0)]
+    if not vectors:
+        rc = _hip.lanczos_hip_crs(C.byref(s), eig.ctypes.data_as(_dp), None, nth_eig, max_iter, threshold)
+        return rc, eig[:max(nth_eig, 0)]
+    y = np.zeros((max(nth_eig, 1), a.dimension))
+    ptrs = (C.c_void_p * y.shape[0])(*[y[i].ctypes.data for i in range(y.shape[0])])
+    old = os.environ.get("LANCZOS_HIP_EIGENVECTORS")
+    os.environ["LANCZOS_HIP_EIGENVECTORS"] = "1"
+    try:
+        rc = _hip.lanczos_hip_crs(C.byref(s), eig.ctypes.data_as(_dp), ptrs, nth_eig, max_iter, threshold)
+    finally:
+        if old is None:
+            del os.environ["LANCZOS_HIP_EIGENVECTORS"]
+        else:
+            os.environ["LANCZOS_HIP_EIGENVECTORS"] = old
+    return rc, eig[:max(nth_eig, 0)], y[:max(nth_eig, 0)]
 
 
 BLOCK_WIDTH = 16

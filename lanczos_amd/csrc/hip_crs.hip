@@ -44,7 +44,10 @@ int env_reorth() {
 
 extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[], int nth_eig,
                                int max_iter, double threshold) {
-    (void)eigenvectors;  // neither reference solver fills them (src/lanczos.c:20, src/lanczos_cuda.c:284)
+    // Neither reference solver fills `eigenvectors` (src/lanczos.c:20, src/lanczos_cuda.c:284), and the
+    // reference's driver passes an uninitialised pointer array (src/main.c:20): it is only written to
+    // when LANCZOS_HIP_EIGENVECTORS=1 says that the caller's pointers are real.
+    const bool want_vectors = eigenvectors != NULL && env_int("LANCZOS_HIP_EIGENVECTORS", 0) != 0;
     if (mat == NULL || eigenvalues == NULL) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
     if (mat->dimension > (size_t)INT_MAX) {                       // src/lanczos_cuda.c:319-322
         printf("Matrix dimension too large for HIP CRS (dim=%zu)\n", mat->dimension);
@@ -85,6 +88,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
     std::vector<double> a((size_t)max_iter, 0.0), b((size_t)max_iter, 0.0), last((size_t)nth_eig, 0.0);
     const int total = max_iter - 1;
     int enq = 0;
+    int steps_used = 0;
     bool reached_max = true;
 
     if (lz::Engine::create(&e, (int64_t)mat->dimension, (int64_t)mat->length, mat->row_head_indexes,
@@ -143,6 +147,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             printf("\n");
             status = EXIT_SUCCESS;
             reached_max = false;
+            steps_used = k + 1;
             break;
         }
         if (!quiet) {  // src/lanczos.c:134-138
@@ -154,13 +159,30 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             printf("%.7f beta converged\n", beta);
             status = EXIT_SUCCESS;
             reached_max = false;
+            steps_used = k + 1;
             break;
         }
         b[(size_t)k] = beta;  // T(k,k+1), src/lanczos.c:189-190
     }
     if (reached_max) {
         status = EXIT_SUCCESS;
+        steps_used = total;
         printf("Reached max iterations (%d)\n", max_iter);  // src/lanczos.c:193
+    }
+    if (want_vectors && steps_used > 0) {
+        // eigenvectors[i][0..n) = Ritz vector of eigenvalues[i], i < min(nth_eig, steps): one pass over
+        // the resident basis per eight vectors
+        const int m = std::min(nth_eig, steps_used);
+        const size_t n = mat->dimension;
+        std::vector<double> y((size_t)m * n), ev((size_t)m);
+        if (lanczos_hip_ritz_vectors(reinterpret_cast<lanczos_hip_engine *>(e), steps_used, m, ev.data(), y.data(),
+                                     NULL) != 0) {
+            printf("%s\n", lanczos_hip_last_error());
+            status = EXIT_FAILURE;
+        } else {
+            for (int i = 0; i < m; i++)
+                if (eigenvectors[i]) memcpy(eigenvectors[i], y.data() + (size_t)i * n, sizeof(double) * n);
+        }
     }
 
 cleanup:

@@ -643,3 +643,26 @@ def test_driver_binary_on_matrix_market_file(gpu, tmp_path):
     assert f"mat dim: {n}" in p.stdout and f"mat num-of-non-zero: {r.size}" in p.stdout
     eig = [float(ln.split("\t")[-1]) for ln in p.stdout.splitlines() if ln.startswith("eigenvalue")]
     assert len(eig) == 4 and np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12
+
+
+def test_dropin_fills_eigenvectors_on_request(gpu):
+    """LANCZOS_HIP_EIGENVECTORS=1: the `eigenvectors` argument both reference solvers ignore
+    (src/lanczos.c:20, src/lanczos_cuda.c:284) receives the Ritz vectors; without it nothing is written."""
+    a = la.synth_laplacian(1, 200)          # simple eigenvalues; 200 steps span the whole space
+    n = a.dimension
+    rc, eig, y = la.lanczos_hip_crs(a, 3, 201, 0.0, vectors=True)
+    assert rc == 0 and y.shape == (3, n)
+    want = laplacian_eigs(1, 200, 3)
+    assert np.max(np.abs(eig - want) / want) < 1e-10
+    for i in range(3):
+        r = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, y[i]) - eig[i] * y[i]
+        assert abs(np.linalg.norm(y[i]) - 1) < 1e-10 and np.linalg.norm(r) < 1e-8, (i, np.linalg.norm(r))
+    assert abs(y[0] @ y[1]) < 1e-10 and abs(y[0] @ y[2]) < 1e-10 and abs(y[1] @ y[2]) < 1e-10
+    # off by default: a pointer array handed in stays untouched
+    import ctypes as C
+    buf = np.full((3, n), 7.0)
+    ptrs = (C.c_void_p * 3)(*[buf[i].ctypes.data for i in range(3)])
+    e2 = np.zeros(3)
+    s = a.as_struct()
+    assert la._hip.lanczos_hip_crs(C.byref(s), e2.ctypes.data_as(la._dp), ptrs, 3, 101, 0.0) == 0
+    assert np.all(buf == 7.0)
