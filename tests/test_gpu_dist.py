@@ -40,7 +40,8 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
         a_local = la.synth_laplacian_rows(3, N, bounds[rank], bounds[rank + 1])
         full = la.synth_laplacian(3, N) if rank == 0 else None
     else:
-        full = la.synth_random_symmetric(30000, 8, 3)
+        # "random_big": rows reach across more of x than the caches hold, so the slabs take the tiled SpMV
+        full = la.synth_random_symmetric(2_600_000 if kind == "random_big" else 30000, 8, 3)
         n = full.dimension
         bounds = ld.partition_rows_by_nnz(full.row_head_indexes, world)
         h = full.row_head_indexes
@@ -57,7 +58,8 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
             e.set_start(v0)
             a1, b1 = e.run(steps)
         q.put((runner.plan.mode, float(np.max(np.abs(alpha - a1) / np.abs(a1))),
-               float(np.max(np.abs(beta - b1) / np.abs(b1)))))
+               float(np.max(np.abs(beta - b1) / np.abs(b1))), runner.engine.e.spmv_name,
+               runner.interior is not None))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -67,6 +69,10 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     ("lap3d", "allgather", "none", "allgather"),
     ("lap3d", "auto", "full2", "halo"),
     ("random", "auto", "full", "allgather"),
+    ("lap3d", "auto", "none", "halo"),
+    ("lap3d", "auto", "selective", "halo"),
+    ("lap3d", "auto", "cuda_compat", "halo"),
+    ("random_big", "auto", "none", "allgather"),
 ])
 def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
     ctx = mp.get_context("spawn")
@@ -75,12 +81,16 @@ def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, kind, mode, reorth, 30, q)) for r in range(2)]
     for p in procs:
         p.start()
-    chosen, ea, eb = q.get(timeout=300)
+    chosen, ea, eb, kernel, overlapped = q.get(timeout=300)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert chosen == expect
     assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+    if kind == "lap3d" and expect == "halo":
+        assert kernel.startswith("dict") and overlapped      # split product, remote entries in the vectors' tails
+    if kind == "random_big":
+        assert kernel.startswith("panel")
 
 
 def test_bench_distributed_code_path_with_one_rank(gpu):
