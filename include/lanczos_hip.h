@@ -86,6 +86,11 @@ typedef struct crs {
  *   LANCZOS_HIP_WINDOW  iterations enqueued ahead of the one the host is looking at (default 4)
  *   LANCZOS_HIP_PROFILE 0 drops the per-kernel events behind the [TOTAL] lines (default 1)
  *   LANCZOS_HIP_JSON    1 adds one JSON line with the same split to stderr
+ *   LANCZOS_HIP_CHECKPOINT  path of a checkpoint file, written every LANCZOS_HIP_CHECKPOINT_EVERY
+ *                       iterations (0 = never, the default) beside the target and renamed over it
+ *   LANCZOS_HIP_RESUME  path of such a file: the run continues from it (same matrix and
+ *                       reorthogonalisation mode; max_iter may be larger) and ends bit for bit
+ *                       as the uninterrupted run would have
  *   LANCZOS_HIP_EIGENVECTORS 1 fills the eigenvectors argument (off by default: the reference's
  *                       driver hands in an uninitialised pointer array, src/main.c:20)
  * and, read by every engine at creation:
@@ -312,8 +317,8 @@ int lanczos_hip_ritz_vectors(lanczos_hip_engine *e, int steps, int m, double *ei
  * Checkpoint / resume (the reference keeps V and T only in memory and frees them at
  * exit, src/lanczos.c:195-207).  save writes alpha/beta of the iterations done,
  * every resident basis vector and the pending partial sums to `path`; load
- * restores them into an engine created for the same matrix, max_iter and reorth
- * mode, after which lanczos_hip_run continues bit for bit.  Single-GPU engines.
+ * restores them into an engine created for the same matrix and reorth mode (max_iter may be
+ * larger), after which lanczos_hip_run continues bit for bit.  Single-GPU engines.
  */
 int lanczos_hip_checkpoint_save(lanczos_hip_engine *e, const char *path);
 int lanczos_hip_checkpoint_load(lanczos_hip_engine *e, const char *path);
@@ -431,6 +436,8 @@ int lanczos_hip_omega_reorths(const lanczos_hip_omega *o);
 size_t lanczos_hip_omega_state_doubles(const lanczos_hip_omega *o);
 void lanczos_hip_omega_state_save(const lanczos_hip_omega *o, double *out);
 int lanczos_hip_omega_state_load(lanczos_hip_omega *o, const double *in);
+/* a state saved by a tracker created for another number of steps, laid out for this one */
+int lanczos_hip_omega_state_fit(const lanczos_hip_omega *o, const double *in, size_t in_doubles, double *out);
 /* steps of this engine's current run that reorthogonalised (every step but the
  * first under the fixed rules) */
 int lanczos_hip_reorth_steps(const lanczos_hip_engine *e);

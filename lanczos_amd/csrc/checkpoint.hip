@@ -98,7 +98,7 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     // the engine must have been created for the same matrix shape and mode
     if (h.n != e->n || h.ldv != e->ldv || h.reorth != e->reorth || h.max_blocks != e->max_blocks ||
         h.lazy != (int)e->lazy || h.k > e->hist_cap ||
-        (size_t)h.tracker_doubles != lanczos_hip_omega_state_doubles(e->omega) || (e->reorth != LANCZOS_HIP_REORTH_NONE && h.k + 1 > e->nvec)) {
+        (h.tracker_doubles != 0) != (e->omega != nullptr) || (e->reorth != LANCZOS_HIP_REORTH_NONE && h.k + 1 > e->nvec)) {
         fclose(fp);
         return lz::fail("lanczos_hip_checkpoint_load: checkpoint (n=%lld, reorth=%d, k=%d) does not fit this engine "
                         "(n=%lld, reorth=%d, max_iter=%d)", (long long)h.n, h.reorth, h.k, (long long)e->n, e->reorth,
@@ -108,7 +108,11 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     std::vector<double> stage(std::min(kChunk, (size_t)e->ldv * (size_t)std::max(slots, 1)));
     std::vector<double> tracker((size_t)h.tracker_doubles);
     int bad = fread(tracker.data(), sizeof(double), tracker.size(), fp) != tracker.size();
-    if (!bad && e->omega) bad = lanczos_hip_omega_state_load(e->omega, tracker.data()) != 0;
+    if (!bad && e->omega) {  // the saving engine may have been created for another max_iter
+        std::vector<double> fitted(lanczos_hip_omega_state_doubles(e->omega));
+        bad = lanczos_hip_omega_state_fit(e->omega, tracker.data(), tracker.size(), fitted.data()) != 0 ||
+              lanczos_hip_omega_state_load(e->omega, fitted.data()) != 0;
+    }
     bad = bad || hipMemset(e->d_V, 0, sizeof(double) * (size_t)e->ldv * (size_t)e->nvec) != hipSuccess;
     bad = bad || copy_in(fp, e->d_alpha, (size_t)h.k, stage) || copy_in(fp, e->d_beta, (size_t)h.k, stage);
     bad = bad || copy_in(fp, e->d_scal, 8, stage);

@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <chrono>
+#include <string>
 #include <vector>
 
 #include "engine.h"
@@ -89,7 +90,11 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
     const int total = max_iter - 1;
     int enq = 0;
     int steps_used = 0;
+    int replayed = 0;
     bool reached_max = true;
+    const char *ckpt_path = getenv("LANCZOS_HIP_CHECKPOINT");
+    const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
+    const char *resume_path = getenv("LANCZOS_HIP_RESUME");
 
     if (lz::Engine::create(&e, (int64_t)mat->dimension, (int64_t)mat->length, mat->row_head_indexes,
                            mat->column_index, mat->values, max_iter, &opt) != 0)
@@ -99,6 +104,13 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
         std::vector<double> v0(mat->dimension);
         lanczos_hip_gaussian_fill(seed, 0, (int64_t)mat->dimension, v0.data());
         if (e->set_start(v0.data(), true, 1.0) != 0) goto cleanup;
+    }
+    if (resume_path && *resume_path) {
+        // continue a run saved by LANCZOS_HIP_CHECKPOINT: the engine takes up where it was (bit for bit),
+        // the host replays its checks on the restored alpha/beta without printing them again
+        if (lanczos_hip_checkpoint_load(reinterpret_cast<lanczos_hip_engine *>(e), resume_path) != 0) goto cleanup;
+        enq = replayed = std::min(e->k, total);
+        fprintf(stderr, "[INIT] name=resumed iterations=%d\n", replayed);
     }
     for (auto &ev : done)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -118,7 +130,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             }
             enq++;
         }
-        if (hipEventSynchronize(done[(size_t)(k % window)]) != hipSuccess) {
+        if (k >= replayed && hipEventSynchronize(done[(size_t)(k % window)]) != hipSuccess) {
             lz::fail("hipEventSynchronize failed");
             goto cleanup;
         }
@@ -150,7 +162,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             steps_used = k + 1;
             break;
         }
-        if (!quiet) {  // src/lanczos.c:134-138
+        if (!quiet && k >= replayed) {  // src/lanczos.c:134-138
             printf("%d\t", k + 1);
             for (int i = 0; i < nth_eig; i++) printf("%.7f\t", eigenvalues[i]);
             printf("\n");
@@ -163,6 +175,15 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             break;
         }
         b[(size_t)k] = beta;  // T(k,k+1), src/lanczos.c:189-190
+        if (ckpt_path && *ckpt_path && ckpt_every > 0 && k >= replayed && (k + 1) % ckpt_every == 0) {
+            // written beside the target and renamed: a crash while writing leaves the previous file whole
+            const std::string tmp = std::string(ckpt_path) + ".tmp";
+            if (lanczos_hip_checkpoint_save(reinterpret_cast<lanczos_hip_engine *>(e), tmp.c_str()) != 0 ||
+                rename(tmp.c_str(), ckpt_path) != 0) {
+                lz::fail("checkpoint to %s failed", ckpt_path);
+                goto cleanup;
+            }
+        }
     }
     if (reached_max) {
         status = EXIT_SUCCESS;

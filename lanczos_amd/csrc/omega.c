@@ -156,3 +156,20 @@ int lanczos_hip_omega_state_load(lanczos_hip_omega *o, const double *in) {
     memcpy(o->w_cur, in + 4 + 2 * (size_t)o->cap + row, row * sizeof(double));
     return 0;
 }
+
+/* A state saved by a tracker of another capacity, laid out for this one (zeros beyond what was saved).
+ * -1 when the saved state holds more steps than this tracker can. */
+int lanczos_hip_omega_state_fit(const lanczos_hip_omega *o, const double *in, size_t in_doubles, double *out) {
+    if (!o || !in || !out || in_doubles < 8 || (in_doubles - 8) % 4 != 0) return -1;
+    const size_t cap_in = (in_doubles - 8) / 4, cap = (size_t)o->cap;
+    const size_t row_in = cap_in + 2, row = cap + 2;
+    if (in[0] < 0 || (size_t)in[0] > cap) return -1;
+    const size_t keep = cap_in < cap ? cap_in : cap, keep_row = row_in < row ? row_in : row;
+    memset(out, 0, lanczos_hip_omega_state_doubles(o) * sizeof(double));
+    memcpy(out, in, 4 * sizeof(double));
+    memcpy(out + 4, in + 4, keep * sizeof(double));
+    memcpy(out + 4 + cap, in + 4 + cap_in, keep * sizeof(double));
+    memcpy(out + 4 + 2 * cap, in + 4 + 2 * cap_in, keep_row * sizeof(double));
+    memcpy(out + 4 + 2 * cap + row, in + 4 + 2 * cap_in + row_in, keep_row * sizeof(double));
+    return 0;
+}

@@ -666,3 +666,30 @@ def test_dropin_fills_eigenvectors_on_request(gpu):
     s = a.as_struct()
     assert la._hip.lanczos_hip_crs(C.byref(s), e2.ctypes.data_as(la._dp), ptrs, 3, 101, 0.0) == 0
     assert np.all(buf == 7.0)
+
+
+@pytest.mark.parametrize("reorth", ["full", "selective", "none"])
+def test_dropin_checkpoints_and_resumes(gpu, tmp_path, reorth):
+    """LANCZOS_HIP_CHECKPOINT / _EVERY / LANCZOS_HIP_RESUME: a run picked up from the last checkpoint ends
+    with the eigenvalues of the uninterrupted run, bit for bit, and prints only the iterations it ran."""
+    a = la.synth_laplacian(2, 100)
+    ck = str(tmp_path / "run.ckpt")
+    base = {"LANCZOS_HIP_REORTH": reorth, "LANCZOS_HIP_JSON": "1"}
+    whole, out_whole, _ = run_dropin(a, 4, 101, 0.0, env=base)
+    # the "interrupted" run: same matrix, stops at 70 iterations, checkpoints every 30 (the file holds >= 60)
+    part, _, err_part = run_dropin(a, 4, 71, 0.0, env=dict(base, LANCZOS_HIP_CHECKPOINT=ck,
+                                                            LANCZOS_HIP_CHECKPOINT_EVERY="30"))
+    assert os.path.exists(ck) and not os.path.exists(ck + ".tmp")
+    resumed, out_res, err_res = run_dropin(a, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=ck))
+    assert resumed["rc"] == 0 and resumed["eig"] == whole["eig"]
+    saved = int([ln for ln in err_res.splitlines() if ln.startswith("[INIT] name=resumed")][0].split("=")[-1])
+    assert 60 <= saved <= 70
+    its = [int(ln.split("\t")[0]) for ln in out_res.splitlines() if ln[:1].isdigit() and "\t" in ln]
+    assert its == list(range(saved + 1, 101))
+    info = json.loads([ln for ln in err_res.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
+    assert info["iterations"] == 100
+    # a file that is no checkpoint is refused
+    bad = str(tmp_path / "bad.ckpt")
+    open(bad, "wb").write(b"not a checkpoint")
+    res_bad, _, _ = run_dropin(a, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=bad))
+    assert res_bad["rc"] != 0
