@@ -604,6 +604,8 @@ class Engine:
         _check(_hip.lanczos_hip_set_start_seed(self._h, seed), "lanczos_hip_set_start_seed")
 
     def run(self, steps: int):
+        """`steps` more iterations; returns alpha and beta of THESE iterations (history(count) gives
+        the whole sequence of a run continued over several calls)."""
         alpha, beta = np.zeros(steps), np.zeros(steps)
         _check(_hip.lanczos_hip_run(self._h, steps, alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp)),
                "lanczos_hip_run")
