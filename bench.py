@@ -57,6 +57,9 @@ def parse_args():
     ap.add_argument("--big-grid", type=int, default=512,
                     help="grid size N of the N^3 Laplacian of the strong-scaling section (SpMV + vector step, "
                          "no reorthogonalisation: the basis of 300 vectors would not fit one GPU); 0 skips it")
+    ap.add_argument("--converge-steps", type=int, default=1200,
+                    help="steps of the time-to-solution section (selective reorthogonalisation, whole basis "
+                         "resident: 1200 vectors of the 256^3 problem are 161 GB); 0 skips it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")
@@ -357,6 +360,26 @@ def single_gpu(args) -> dict:
                 "ms_per_step": dts / K * 1e3,
                 "steps_that_reorthogonalised": es.reorth_steps,
                 "ritz_rel_diff_vs_full": float(np.max(np.abs(ritz_s - ritz) / np.abs(ritz))),
+            }
+    # time to solution: selective reorthogonalisation until the lowest eigenvalue stands (closed form known)
+    if args.converge_steps > 0 and d == 3:
+        S = args.converge_steps
+        one = 2.0 - 2.0 * np.cos(np.pi / (N + 1))
+        exact = 3.0 * one
+        with la.Engine(a, S + 1, reorth="selective", spmv=args.spmv) as ec:
+            ec.set_start(v0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ec.run(S)
+            torch.cuda.synchronize()
+            dtc = time.perf_counter() - t0
+            a_c, b_c = ec.history(S)
+            lowest = float(la.ritz_values(a_c, b_c, S, 1)[0])
+            out["converged_run"] = {
+                "reorth": "selective", "steps": S, "seconds": dtc, "iters_per_s": S / dtc,
+                "steps_that_reorthogonalised": ec.reorth_steps,
+                "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
+                "basis_GB": (S + 1) * 8.0 * n / 1e9,
             }
     out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, K, args.reorth)
     if not args.no_block:

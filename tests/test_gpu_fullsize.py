@@ -69,7 +69,7 @@ def test_bench_line_keeps_its_contract(gpu):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "2",
-                        "--cpu-steps", "6", "--rand-rows", "300000", "--big-grid", "128"], capture_output=True, text=True, timeout=600,
+                        "--cpu-steps", "6", "--rand-rows", "300000", "--big-grid", "128", "--converge-steps", "40"], capture_output=True, text=True, timeout=600,
                        cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -89,3 +89,4 @@ def test_bench_line_keeps_its_contract(gpu):
     assert d["spmv_vector_step"]["iters_per_s"] > 0 and d["random_symmetric"]["iters_per_s"] > 0
     assert d["selective_reorth"]["ritz_rel_diff_vs_full"] < 1e-10
     assert d["strong_scaling_laplacian"]["iters_per_s"] > 0
+    assert d["converged_run"]["steps"] == 40 and d["converged_run"]["seconds"] > 0
