@@ -100,11 +100,12 @@ def test_bench_distributed_code_path_with_one_rank(gpu):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", LOCAL_RANK="0",
                WORLD_SIZE="1")
     p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--workload", "lap64", "--steps", "40",
-                        "--warmup", "2", "--big-grid", "96", "--rand-rows", "200000"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+                        "--warmup", "2", "--big-grid", "96", "--rand-rows", "200000", "--converge-steps", "60"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["steps"] == 40 and out["value"] > 0
     assert out["strong_scaling_laplacian"]["iters_per_s"] > 0 and out["random_symmetric"]["iters_per_s"] > 0
+    assert out["converged_run"]["steps"] == 60 and out["converged_run"]["seconds"] > 0
     import lanczos_amd as la
     a = la.synth_laplacian(3, 64)
     with la.Engine(a, 41) as e:
