@@ -188,3 +188,55 @@ def test_split_product_matches_the_whole_one(gpu, kind):
         assert np.max(np.abs(basis[1, :n].cpu().numpy() - whole)) < 1e-14 and abs(float(red[0]) - dot) < 1e-13 * abs(dot)
         with pytest.raises(la.LanczosHipError, match="row range"):
             e.phase_spmv_begin(10, 5)
+
+
+def test_split_product_on_random_banded_matrices(gpu):
+    """Random sizes, row lengths, band widths and interior ranges through every SpMV form that can be
+    split: the two-part product equals the one-part product row by row."""
+    import torch
+    import lanczos_amd as la
+    rng = np.random.default_rng(314)
+    red = torch.zeros(16, dtype=torch.float64, device="cuda")
+    for case in range(40):
+        n = int(rng.choice([65, 129, 1000, 4097, int(rng.integers(200, 30000))]))
+        if case % 4 == 0:                       # a stencil, so that the dictionary form takes it
+            a = la.synth_laplacian(1, n) if case % 8 else la.synth_laplacian(2, int(np.sqrt(n)) + 2)
+            n = a.dimension
+            kinds = ["auto"]
+        else:
+            lens = rng.integers(0, 9, n)
+            lens[rng.integers(0, n)] = int(rng.integers(1, 700))          # one long row
+            head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            w = int(rng.integers(1, 300))
+            rows = np.repeat(np.arange(n), lens)
+            cols = np.clip(rows + rng.integers(-w, w + 1, head[-1]), 0, n - 1).astype(np.int64)
+            a = la.CrsMatrix(rng.standard_normal(head[-1]), cols, head)
+            kinds = ["stream", "vector"] + (["rows"] if lens.max() <= 8 else [])
+        base = la.gather_base(n)
+        basis = torch.zeros(3, base + 2048, dtype=torch.float64, device="cuda")
+        v0 = rng.standard_normal(n)
+        for kind in kinds:
+            try:
+                e = la.Engine(a, 5, reorth="none", spmv=kind, n_global=n, n_ext=base, basis=basis.data_ptr(),
+                              basis_ld=base + 2048)
+            except la.LanczosHipError as ex:
+                assert "needs" in str(ex)
+                continue
+            with e:
+                if not e.can_overlap:
+                    continue
+                e.set_start_scaled(v0, 1.0)
+                e.phase_spmv(red.data_ptr())
+                torch.cuda.synchronize()
+                whole, dot = basis[1, :n].cpu().numpy().copy(), float(red[0])
+                lo = int(rng.integers(0, n + 1))
+                hi = int(rng.integers(lo, n + 1))
+                basis[1].zero_()
+                e.phase_spmv_begin(lo, hi)
+                e.phase_spmv_end(red.data_ptr())
+                torch.cuda.synchronize()
+                split = basis[1, :n].cpu().numpy()
+                scale = np.abs(whole).max() + 1e-300
+                assert np.max(np.abs(split - whole)) <= 1e-13 * scale, (case, kind, n, lo, hi)
+                assert abs(float(red[0]) - dot) <= 1e-12 * (np.abs(whole) @ np.abs(v0) + 1e-300), (case, kind)
+                assert not basis[1, n:].any()
