@@ -93,6 +93,26 @@ def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
         assert kernel.startswith("panel")
 
 
+@pytest.mark.parametrize("switch,reorth", [("LANCZOS_DIST_NO_INPLACE", "none"), ("LANCZOS_DIST_NO_INPLACE", "full"),
+                                           ("LANCZOS_DIST_NO_OVERLAP", "full")])
+def test_two_ranks_with_the_other_exchange_forms(gpu, monkeypatch, switch, reorth):
+    """The gather-buffer form of the halo exchange, and exchange-then-product, stay selectable for
+    comparisons on a real node: same results."""
+    monkeypatch.setenv(switch, "1")      # inherited by the spawned ranks
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "lap3d", "auto", reorth, 30, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    chosen, ea, eb, kernel, overlapped = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert chosen == "halo" and not overlapped
+    assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+
+
 def test_bench_distributed_code_path_with_one_rank(gpu):
     """bench.py's N > 1 path (nccl process group, halo/allgather plumbing) with world size 1."""
     import json
