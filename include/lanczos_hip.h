@@ -262,6 +262,21 @@ int lanczos_hip_iterations(const lanczos_hip_engine *e);
  * src/lanczos_cuda.c:562-577). */
 int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host);
 
+/*
+ * The same product on DEVICE vectors, without any allocation: y_dev[0..n) = A x_dev[0..n_ext) and,
+ * when dot_dev is not NULL, dot_dev[0] = x_dev[0..n) . y_dev, enqueued on the engine's stream (the
+ * call does not wait for it).  No counterpart in the reference.  It is for callers that cannot
+ * allocate: a stream under HIP graph capture, a tight serving loop, a harness that forbids
+ * hipMalloc -- lanczos_hip_spmv stages its host vectors through two hipMalloc'd buffers per call.
+ * The kernels are the ones lanczos_hip_spmv runs (y is bit for bit the same); their scratch memory
+ * (per-workgroup partial sums and, on the merge SpMV, the rows shared between tiles) is a fixed
+ * array of 3 178 496 bytes in the library's device image, one copy per GPU, held until the
+ * process ends.  Limits: on the merge SpMV at most 67 108 864 entries, otherwise none beyond the
+ * engine's own; beyond it the call fails with a message and launches nothing.  Calls on the same
+ * GPU share the array: two that overlap in time (different streams or threads) race on it.
+ */
+int lanczos_hip_spmv_noalloc(lanczos_hip_engine *e, const double *x_dev, double *y_dev, double *dot_dev);
+
 /* Copy basis vector k (n doubles) to the host. */
 int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host);
 

@@ -98,6 +98,8 @@ _hip.lanczos_hip_omega_reorths.argtypes = [C.c_void_p]
 _hip.lanczos_hip_omega_reorths.restype = C.c_int
 _hip.lanczos_hip_spmv.argtypes = [C.c_void_p, _dp, _dp]
 _hip.lanczos_hip_spmv.restype = C.c_int
+_hip.lanczos_hip_spmv_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+_hip.lanczos_hip_spmv_noalloc.restype = C.c_int
 _hip.lanczos_hip_get_vector.argtypes = [C.c_void_p, C.c_int, _dp]
 _hip.lanczos_hip_get_vector.restype = C.c_int
 _hip.lanczos_hip_profile.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp]
@@ -616,6 +618,10 @@ class Engine:
         y = np.empty(self.n)
         _check(_hip.lanczos_hip_spmv(self._h, x.ctypes.data_as(_dp), y.ctypes.data_as(_dp)), "lanczos_hip_spmv")
         return y
+
+    def spmv_noalloc(self, x_dev: int, y_dev: int, dot_dev: int | None = None):
+        """y = A x on device addresses (enqueued on the engine's stream), no allocation."""
+        _check(_hip.lanczos_hip_spmv_noalloc(self._h, x_dev, y_dev, dot_dev), "lanczos_hip_spmv_noalloc")
 
     def get_vector(self, k: int):
         out = np.empty(self.n)

@@ -149,6 +149,7 @@ struct Engine {
     int selective_lazy_tail();
     int run(int steps, double *alpha_out, double *beta_out);
     int spmv_host(const double *x_host, double *y_host);
+    int spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev);
     int enable_host_history();
 
     hipEvent_t take_event();
