@@ -103,17 +103,21 @@ def cpu_baseline(a, v0, steps: int) -> dict:
     }
 
 
-def measured_traffic(kernel_class: str, workload: str, steps: int, reorth: str):
-    """HBM bytes per launch of one kernel class from the PMC passes (FETCH_SIZE, WRITE_SIZE, collected by
-    rocprofv3 in runs of their own over this same command and condensed into profiles/traffic.json by
-    scripts/summarize_profile.py); None when no such measurement exists for this configuration."""
+def measured_traffic(kernel_class: str, workload: str, reorth: str, algorithmic_bytes_per_launch: float):
+    """HBM bytes per launch of one kernel class: the ratio (measured bytes / algorithmic bytes) that the
+    PMC passes gave for that class (FETCH_SIZE and WRITE_SIZE collected by rocprofv3 in runs of their
+    own over this command, condensed into profiles/traffic.json by scripts/summarize_profile.py) times
+    the algorithmic bytes of this run's launches.  The ratio does not depend on the number of steps
+    (the reorthogonalisation kernels read the k basis vectors once whatever k is), so the record holds
+    for any --steps.  None when no measurement exists for this workload and reorthogonalisation mode."""
     try:
         rec = json.load(open(os.path.join(HERE, "profiles", "traffic.json")))
     except (OSError, ValueError):
         return None
-    if (rec.get("workload"), rec.get("steps"), rec.get("reorth")) != (workload, steps, reorth):
+    if (rec.get("workload"), rec.get("reorth")) != (workload, reorth):
         return None
-    return rec.get("bytes_per_launch", {}).get(kernel_class)
+    ratio = rec.get("measured_over_algorithmic", {}).get(kernel_class)
+    return None if ratio is None else ratio * algorithmic_bytes_per_launch
 
 
 def block_variant(la, a, steps: int = 8) -> dict:
@@ -307,6 +311,12 @@ def single_gpu(args) -> dict:
             "spmv_GBps": spmv_gb,
             "spmv_frac_of_hbm_peak": spmv_gb / HBM_PEAK_GBPS,
             "kernel_ms_per_iter": {k: v["ms"] / S for k, v in p2.items()},
+            # the vector part two ways: the shared figure charges 64 n per step (alpha dot 16 n, recurrence
+            # 32 n, scaling 16 n); the deferred-normalisation recurrence this mode runs moves 32 n
+            "bytes_charged": fmt_spmv + 64.0 * n,
+            "bytes_moved": fmt_spmv + 32.0 * n,
+            "frac_of_hbm_peak_charged": (fmt_spmv + 64.0 * n) * S / dt2 / 1e9 / HBM_PEAK_GBPS,
+            "frac_of_hbm_peak_moved": (fmt_spmv + 32.0 * n) * S / dt2 / 1e9 / HBM_PEAK_GBPS,
         }
 
     sv = vector_step(args.spmv)
@@ -381,7 +391,8 @@ def single_gpu(args) -> dict:
                 "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
                 "basis_GB": (S + 1) * 8.0 * n / 1e9,
             }
-    out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, K, args.reorth)
+    out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, args.reorth,
+                                                  out["roofline"]["algorithmic_bytes_per_launch"])
     if not args.no_block:
         out["block_variant"] = block_variant(la, a)
     if args.rand_rows > 0:
@@ -411,8 +422,42 @@ def single_gpu(args) -> dict:
     return out
 
 
+def launch_command(argv, gpus: int, port: int) -> list:
+    """The command that starts one rank per GPU on this node for `bench.py <argv>`."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv) -> int:
+    """`bench.py --gpus N` called without a launcher around it: the ranks are started as a child
+    process (this process has not touched the GPU and never will), rank 0's JSON line is relayed,
+    the child's exit code is returned."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(launch_command(argv, args.gpus, port), stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for cand in p.stdout.splitlines():
+        cand = cand.strip()
+        if cand.startswith("{") and '"metric"' in cand:
+            line = cand
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
 def main():
     args = parse_args()
+    if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))
     # stdout carries the one JSON line and nothing else: whatever libraries print while the run
     # lasts (RCCL's version banner goes to stdout) is sent to stderr instead
     sys.stdout.flush()

@@ -95,6 +95,8 @@ typedef struct crs {
  *                       driver hands in an uninitialised pointer array, src/main.c:20)
  * and, read by every engine at creation:
  *   LANCZOS_HIP_NO_DICT    1 keeps the CRS kernels on matrices whose rows repeat
+ *   LANCZOS_HIP_PIN_UPLOAD 0 uploads from pageable memory (default: the caller's arrays are page-locked
+ *                          around the copies, as src/lanczos_cuda.c:144, 168 do)
  *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 18)
  */
 int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
@@ -250,7 +252,7 @@ void lanczos_hip_gaussian_fill(uint64_t seed, int64_t row_begin, int64_t n, doub
  * without host round trips, then return alpha_k and beta_k of those
  * iterations (host arrays of `steps` doubles; either may be NULL).  Blocks
  * until the stream has drained.  At most max_iter - 1 iterations in total
- * (3-vector mode: unlimited).
+ * (3-vector mode: max(max_iter, 65536) per run, the length of the alpha/beta history).
  */
 int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out);
 

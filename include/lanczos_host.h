@@ -92,6 +92,11 @@ int lanczos_synth_laplacian_rows(int d, int64_t N, int64_t row_begin, int64_t ro
  * Rows sorted by column.
  */
 int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Crs *out);
+/* Rows [row_begin, row_end) of the same matrix (column indices stay global): every draw of the whole
+ * matrix is replayed and the entries that land in the slab are kept, so a rank of a row-partitioned
+ * run builds its slab without ever holding the whole matrix. */
+int lanczos_synth_random_symmetric_rows(int64_t n, int per_row, uint64_t seed, int64_t row_begin, int64_t row_end,
+                                        Mat_Crs *out);
 void lanczos_free_crs(Mat_Crs *m);
 
 #ifdef __cplusplus

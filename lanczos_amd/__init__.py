@@ -163,6 +163,9 @@ _host.lanczos_synth_laplacian_rows.argtypes = [C.c_int, C.c_int64, C.c_int64, C.
 _host.lanczos_synth_laplacian_rows.restype = C.c_int
 _host.lanczos_synth_random_symmetric.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.POINTER(Mat_Crs)]
 _host.lanczos_synth_random_symmetric.restype = C.c_int
+_host.lanczos_synth_random_symmetric_rows.argtypes = [C.c_int64, C.c_int, C.c_uint64, C.c_int64, C.c_int64,
+                                                       C.POINTER(Mat_Crs)]
+_host.lanczos_synth_random_symmetric_rows.restype = C.c_int
 _host.lanczos_free_crs.argtypes = [C.POINTER(Mat_Crs)]
 _host.lanczos_free_crs.restype = None
 _libc = C.CDLL(None)
@@ -278,6 +281,14 @@ def synth_random_symmetric(n: int, per_row: int, seed: int) -> CrsMatrix:
     m = Mat_Crs()
     if _host.lanczos_synth_random_symmetric(n, per_row, seed, C.byref(m)) != 0:
         raise ValueError("lanczos_synth_random_symmetric failed")
+    return CrsMatrix._take(m)
+
+
+def synth_random_symmetric_rows(n: int, per_row: int, seed: int, row_begin: int, row_end: int) -> CrsMatrix:
+    """Rows [row_begin, row_end) of synth_random_symmetric(n, per_row, seed); column indices stay global."""
+    m = Mat_Crs()
+    if _host.lanczos_synth_random_symmetric_rows(n, per_row, seed, row_begin, row_end, C.byref(m)) != 0:
+        raise ValueError("lanczos_synth_random_symmetric_rows failed")
     return CrsMatrix._take(m)
 
 

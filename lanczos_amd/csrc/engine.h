@@ -31,6 +31,9 @@ struct Engine {
     int device = -1;
     int cus = 0;
     int max_blocks = 0;    // 8 workgroups per CU, multiple of 8
+    // what the matrix upload took (host arrays page-locked around the copies unless LANCZOS_HIP_PIN_UPLOAD=0)
+    double upload_sec = 0.0, upload_bytes = 0.0;
+    bool upload_pinned = false;
     // device memory
     void *d_rp = nullptr;  // int32 or int64 row offsets
     bool rp64 = false;
@@ -84,6 +87,8 @@ struct Engine {
     // iteration state
     int k = 0;
     bool started = false;
+    int ckpt_host_k = -1;  // iterations whose scalars a pipelined host loop has consumed (-1: all of k); travels
+                           // with a checkpoint so a resumed loop knows which lines were already printed
     // profiling
     bool profile = false;
     double prof_ms[LANCZOS_HIP_K_COUNT] = {0};
@@ -154,6 +159,7 @@ struct Engine {
 
     hipEvent_t take_event();
     void harvest_profile();
+    void harvest_completed();
 };
 
 }  // namespace lz

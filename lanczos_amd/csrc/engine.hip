@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "balance.hip.h"
@@ -83,6 +84,23 @@ void Engine::harvest_profile() {
         if (p.stop) event_pool.push_back(p.stop);
     }
     prof_pending.clear();
+}
+
+// The events of launches that have finished, oldest first; stops at the first launch still running.
+// For a host loop that runs alongside the stream: the list of live events stays as short as the
+// number of launches in flight.
+void Engine::harvest_completed() {
+    size_t done = 0;
+    for (; done < prof_pending.size(); ++done) {
+        auto &p = prof_pending[done];
+        if (!p.start || !p.stop || hipEventQuery(p.stop) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) prof_ms[p.cls] += ms;
+        event_pool.push_back(p.start);
+        event_pool.push_back(p.stop);
+    }
+    (void)hipGetLastError();  // hipErrorNotReady from the query is not an error
+    prof_pending.erase(prof_pending.begin(), prof_pending.begin() + (long)done);
 }
 
 // ---------------------------------------------------------------------------
@@ -196,32 +214,61 @@ int Engine::setup_device(const lanczos_hip_options &opt, int64_t n_, int64_t n_e
     return 0;
 }
 
-// Matrix upload: values as they are, columns narrowed on the device, row offsets
-// narrowed on the host when they fit 32 bits.
+// The caller's array page-locked for the duration of the upload, as the reference does around its
+// copies (src/lanczos_cuda.c:144, 168): the copy engine then reads it directly.  When the
+// registration is refused the copy goes through the runtime's pageable path instead.
+struct HostPin {
+    void *ptr = nullptr;
+    HostPin(const void *p, size_t bytes, bool enable) {
+        if (enable && bytes && hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+            ptr = const_cast<void *>(p);
+        else
+            (void)hipGetLastError();
+    }
+    ~HostPin() {
+        if (ptr) (void)hipHostUnregister(ptr);
+    }
+};
+
+// Matrix upload: values as they are, columns and (when they fit 32 bits) row offsets narrowed on
+// the device from a staging buffer.
 int Engine::upload_crs(const int64_t *rp, const int64_t *ci, const double *va) {
-    if (nnz > 0) {
-        HIP_TRY(hipMemcpyAsync(d_val, va, sizeof(double) * nnz, hipMemcpyHostToDevice, stream));
-        const int64_t chunk = (int64_t)1 << 26;  // 512 MiB of int64 per piece
-        int64_t *stage = nullptr;
-        HIP_TRY(hipMalloc(&stage, sizeof(int64_t) * std::min(chunk, nnz)));
-        for (int64_t off = 0; off < nnz; off += chunk) {
-            const int64_t cnt = std::min(chunk, nnz - off);
-            HIP_TRY(hipMemcpyAsync(stage, ci + off, sizeof(int64_t) * cnt, hipMemcpyHostToDevice, stream));
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    const char *pin_env = getenv("LANCZOS_HIP_PIN_UPLOAD");
+    const bool pin = !(pin_env && *pin_env && atoi(pin_env) == 0);
+    HostPin pin_va(va, sizeof(double) * (size_t)nnz, pin), pin_ci(ci, sizeof(int64_t) * (size_t)nnz, pin),
+        pin_rp(rp, sizeof(int64_t) * (size_t)(n + 1), pin);
+    upload_pinned = pin_va.ptr != nullptr || nnz == 0;
+    const int64_t chunk = (int64_t)1 << 26;  // 512 MiB of int64 per piece
+    int64_t *stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, sizeof(int64_t) * std::min(chunk, std::max(nnz, n + 1))));
+    auto narrow = [&](const int64_t *src, int32_t *dst, int64_t count) -> hipError_t {
+        for (int64_t off = 0; off < count; off += chunk) {
+            const int64_t cnt = std::min(chunk, count - off);
+            hipError_t st = hipMemcpyAsync(stage, src + off, sizeof(int64_t) * cnt, hipMemcpyHostToDevice, stream);
+            if (st != hipSuccess) return st;
             const int blocks = (int)std::min<int64_t>(max_blocks, (cnt + kBlock - 1) / kBlock);
-            hipLaunchKernelGGL(k_narrow_i64, dim3(blocks), dim3(kBlock), 0, stream, stage, d_col + off, cnt);
+            hipLaunchKernelGGL(k_narrow_i64, dim3(blocks), dim3(kBlock), 0, stream, stage, dst + off, cnt);
         }
-        HIP_TRY(hipStreamSynchronize(stream));
-        HIP_TRY(hipFree(stage));
+        return hipGetLastError();
+    };
+    hipError_t st = hipSuccess;
+    if (nnz > 0) {
+        st = hipMemcpyAsync(d_val, va, sizeof(double) * nnz, hipMemcpyHostToDevice, stream);
+        if (st == hipSuccess) st = narrow(ci, d_col, nnz);
     }
-    if (rp64) {
-        HIP_TRY(hipMemcpyAsync(d_rp, rp, 8 * (n + 1), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
-    } else {
-        std::vector<int32_t> rp32((size_t)n + 1);
-        for (int64_t i = 0; i <= n; i++) rp32[(size_t)i] = (int32_t)rp[i];
-        HIP_TRY(hipMemcpyAsync(d_rp, rp32.data(), 4 * (n + 1), hipMemcpyHostToDevice, stream));
-        HIP_TRY(hipStreamSynchronize(stream));
+    if (st == hipSuccess) {
+        if (rp64)
+            st = hipMemcpyAsync(d_rp, rp, 8 * (n + 1), hipMemcpyHostToDevice, stream);
+        else
+            st = narrow(rp, (int32_t *)d_rp, n + 1);
     }
+    if (st == hipSuccess) st = hipStreamSynchronize(stream);
+    (void)hipFree(stage);
+    if (st != hipSuccess) return fail("lanczos_hip: matrix upload failed: %s", hipGetErrorString(st));
+    upload_bytes = 16.0 * (double)nnz + 8.0 * (double)(n + 1);
+    upload_sec = std::chrono::duration<double>(clk::now() - t0).count();
     return 0;
 }
 
@@ -612,7 +659,9 @@ int Engine::check_can_step() {
     if (!started) return fail("lanczos_hip: no start vector set");
     if (reorth != LANCZOS_HIP_REORTH_NONE && k >= max_iter - 1)
         return fail("lanczos_hip: basis full (%d iterations of max_iter=%d done)", k, max_iter);
-    if (k >= hist_cap) return fail("lanczos_hip: history full (%d iterations)", k);
+    if (k >= hist_cap)
+        return fail("lanczos_hip: history full: the three-vector mode records at most max(max_iter, 65536) = %d "
+                    "iterations per run", hist_cap);
     return 0;
 }
 
@@ -787,6 +836,9 @@ int Engine::launch_scale(const double *parts, int cnt) {
 
 int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
     if (lazy_slab) return fail("lanczos_hip_phase_recur: reorth=none on a row slab runs phase_recur_lazy");
+    if (reorth == LANCZOS_HIP_REORTH_MGS)
+        return fail("lanczos_hip_phase_recur: the one-vector-at-a-time order (mgs) is not available phase by phase "
+                    "(it would need one reduction over ranks per basis vector); use full or full2");
     // red[0] holds alpha (already reduced over ranks by the caller)
     if (int rc = launch_recur(red, 1)) return rc;
     int l0, l1;
@@ -1031,8 +1083,8 @@ int Engine::spmv_host(const double *x_host, double *y_host) {
     HIP_TRY(hipMalloc(&dy, sizeof(double) * n));
     HIP_TRY(hipMemcpyAsync(dx, x_host, sizeof(double) * n_ext, hipMemcpyHostToDevice, stream));
     int nparts = 0;
-    // xdot only feeds the alpha partial; any n-vector will do here
-    int rc = launch_spmv(dx, dy, dy, &nparts);
+    // xdot only feeds the alpha partial; the first n entries of x will do here
+    int rc = launch_spmv(dx, dx, dy, &nparts);
     if (rc == 0) {
         hipError_t st = hipMemcpyAsync(y_host, dy, sizeof(double) * n, hipMemcpyDeviceToHost, stream);
         if (st == hipSuccess) st = hipStreamSynchronize(stream);

@@ -90,8 +90,10 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
     const int total = max_iter - 1;
     int enq = 0;
     int steps_used = 0;
-    int replayed = 0;
+    int replayed = 0;  // iterations restored from a checkpoint: their scalars are there, nothing to wait for
+    int printed = 0;   // of those, the ones whose lines the interrupted run had already printed
     bool reached_max = true;
+    int exit_kind = 0;  // 0 max-iter (src/lanczos.c:193), 1 Ritz values stood still (:127-133), 2 beta (:185-188)
     const char *ckpt_path = getenv("LANCZOS_HIP_CHECKPOINT");
     const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
     const char *resume_path = getenv("LANCZOS_HIP_RESUME");
@@ -110,7 +112,8 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
         // the host replays its checks on the restored alpha/beta without printing them again
         if (lanczos_hip_checkpoint_load(reinterpret_cast<lanczos_hip_engine *>(e), resume_path) != 0) goto cleanup;
         enq = replayed = std::min(e->k, total);
-        fprintf(stderr, "[INIT] name=resumed iterations=%d\n", replayed);
+        printed = std::min(std::max(e->ckpt_host_k, 0), replayed);
+        fprintf(stderr, "[INIT] name=resumed iterations=%d printed=%d\n", replayed, printed);
     }
     for (auto &ev : done)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
@@ -118,6 +121,8 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             goto cleanup;
         }
     time_init = now_sec() - t_start;
+    fprintf(stderr, "[INIT] name=upload sec=%.6f bytes=%.0f GBps=%.2f pinned=%d\n", e->upload_sec, e->upload_bytes,
+            e->upload_sec > 0 ? e->upload_bytes / e->upload_sec / 1e9 : 0.0, (int)e->upload_pinned);
     fprintf(stderr, "[INIT] name=total_wall sec=%.6f\n", time_init);
     fprintf(stderr, "[INIT] name=spmv_kernel detail_ref=%s\n", e->spmv_name);
 
@@ -134,6 +139,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             lz::fail("hipEventSynchronize failed");
             goto cleanup;
         }
+        if (k >= replayed) e->harvest_completed();  // keeps the list of live profiling events short
         const double alpha = e->h_hist[2 * (size_t)k];
         const double beta = e->h_hist[2 * (size_t)k + 1];
         a[(size_t)k] = alpha;  // T(k,k), src/lanczos.c:113
@@ -159,10 +165,11 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             printf("\n");
             status = EXIT_SUCCESS;
             reached_max = false;
+            exit_kind = 1;
             steps_used = k + 1;
             break;
         }
-        if (!quiet && k >= replayed) {  // src/lanczos.c:134-138
+        if (!quiet && k >= printed) {  // src/lanczos.c:134-138
             printf("%d\t", k + 1);
             for (int i = 0; i < nth_eig; i++) printf("%.7f\t", eigenvalues[i]);
             printf("\n");
@@ -171,6 +178,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
             printf("%.7f beta converged\n", beta);
             status = EXIT_SUCCESS;
             reached_max = false;
+            exit_kind = 2;
             steps_used = k + 1;
             break;
         }
@@ -178,6 +186,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
         if (ckpt_path && *ckpt_path && ckpt_every > 0 && k >= replayed && (k + 1) % ckpt_every == 0) {
             // written beside the target and renamed: a crash while writing leaves the previous file whole
             const std::string tmp = std::string(ckpt_path) + ".tmp";
+            e->ckpt_host_k = k + 1;  // the engine is up to window - 1 iterations ahead of the lines printed so far
             if (lanczos_hip_checkpoint_save(reinterpret_cast<lanczos_hip_engine *>(e), tmp.c_str()) != 0 ||
                 rename(tmp.c_str(), ckpt_path) != 0) {
                 lz::fail("checkpoint to %s failed", ckpt_path);
@@ -232,9 +241,9 @@ cleanup:
     if (env_int("LANCZOS_HIP_JSON", 0))  // the same split, one machine-readable line
         fprintf(stderr,
                 "{\"lanczos_hip\": {\"status\": %d, \"dimension\": %zu, \"nnz\": %zu, \"iterations\": %d, "
-                "\"reorth_steps\": %d, \"spmv_kernel\": \"%s\", \"sec\": {\"init\": %.6f, \"spmv\": %.6f, "
+                "\"exit_kind\": %d, \"exit_step\": %d, \"reorth_steps\": %d, \"spmv_kernel\": \"%s\", \"sec\": {\"init\": %.6f, \"spmv\": %.6f, "
                 "\"diagonalization\": %.6f, \"reorthogonalization\": %.6f, \"wall\": %.6f}}}\n",
-                status, mat->dimension, mat->length, iterations, reorth_steps, kernel_name, time_init, t_spmv,
+                status, mat->dimension, mat->length, iterations, exit_kind, steps_used, reorth_steps, kernel_name, time_init, t_spmv,
                 time_diag, t_reorth, wall);
     return status;
 }

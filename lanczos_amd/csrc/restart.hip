@@ -17,6 +17,7 @@ extern "C" int lanczos_hip_thick_restart(lanczos_hip_engine *eh, int nth, int ke
                                          int *cycles_out, int *products_out) {
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !eig_out || nth < 1 || max_cycles < 1) return lz::fail("lanczos_hip_thick_restart: bad argument");
+    if (e->slab) return lz::fail("lanczos_hip_thick_restart: not available on a row-partitioned engine");
     const int m = e->max_iter - 1;  // steps that fill the basis
     if (keep < nth || keep + 2 > m)
         return lz::fail("lanczos_hip_thick_restart: need nth <= keep <= max_iter - 3 (nth=%d, keep=%d, max_iter=%d)",

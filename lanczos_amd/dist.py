@@ -504,12 +504,6 @@ def _timed_dist_run(torch, dist, runner, v0, steps, warm):
     return float(t.item())
 
 
-def _slab(a, r0, r1, la):
-    """rows r0..r1-1 of a CrsMatrix, columns still global"""
-    h = a.row_head_indexes
-    return la.CrsMatrix(a.values[h[r0]:h[r1]].copy(), a.column_index[h[r0]:h[r1]].copy(), (h[r0:r1 + 1] - h[r0]).copy())
-
-
 def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
     """bench.py for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
@@ -525,6 +519,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    world = dist.get_world_size()   # what the line reports as n_gpus: the ranks RCCL connected
     comm = Comm(dist, torch, torch.device("cuda", local_rank))
     d, N = workloads[args.workload]
     n = N ** d
@@ -621,11 +616,14 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
     torch.cuda.empty_cache()
     # ---- irregular rows: random symmetric matrix, nnz-balanced slabs, all-gather exchange
     if getattr(args, "rand_rows", 0) > 0:
-        full = la.synth_random_symmetric(args.rand_rows, 10, 42)
-        nr, nnz_r = full.dimension, full.length
-        rb = partition_rows_by_nnz(full.row_head_indexes, world)
-        mine = _slab(full, rb[rank], rb[rank + 1], la)
-        del full
+        # every rank builds its own slab (the rows hold ~21 entries each with little spread, so equal
+        # row counts are equal entry counts to a fraction of a per cent)
+        nr = args.rand_rows
+        rb = partition_rows(nr, world)
+        mine = la.synth_random_symmetric_rows(nr, 10, 42, rb[rank], rb[rank + 1])
+        nz3 = torch.tensor([float(mine.length)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nz3)
+        nnz_r = int(nz3.item())
         r3 = build_gpu_rank(la, torch, comm, mine, rb, 4, reorth="none", spmv=args.spmv, profile=True)
         v3 = la.gaussian_fill(123456789, rb[rank], rb[rank + 1] - rb[rank])
         dt3 = _timed_dist_run(torch, dist, r3, v3, steps2, 5)
@@ -635,7 +633,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             b = algorithmic_bytes(nr, nnz_r)
             out["random_symmetric"] = {
                 "workload": f"random symmetric n={nr}, nnz={nnz_r} ({nnz_r / nr:.1f} per row), seed 42, "
-                            f"nnz-balanced row slabs over {world} GPUs",
+                            f"equal row slabs over {world} GPUs",
                 "steps": steps2,
                 "iters_per_s": steps2 / dt3,
                 "ms_per_iter": dt3 / steps2 * 1e3,

@@ -6,6 +6,7 @@
  * call sites (src/main.c:59, 73), which this build also runs on the GPU.
  * stdout/stderr lines keep the reference's grammar.
  */
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -35,6 +36,7 @@ int main(int argc, const char *argv[]) {
     Mat_Coo mat;
     Mat_Crs mat_crs;
     Mat_Type mat_type;
+    printf("Using %d threads\n", omp_get_max_threads()); /* src/main.c:23 */
     if (argc != 5 || (strcmp(argv[2], "coo") && strcmp(argv[2], "crs") && strcmp(argv[2], "crs_hip"))) {
         fprintf(stderr, "Usage: %s <input_file> <coo|crs|crs_hip> <number_of_eigenvalues> <max_iter>\n", argv[0]);
         return EXIT_FAILURE;

@@ -107,49 +107,56 @@ typedef struct {
     double v;
 } ent_t;
 
-int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Crs *out) {
+/* Rows [row_begin, row_end) of lanczos_synth_random_symmetric(n, per_row, seed): the same entries,
+ * column indices global, so that every rank of a row-partitioned run can build its own slab.  Every
+ * draw of the whole matrix is replayed (counter-based generator, nothing stored) and the ones that
+ * land in the slab, in either orientation, are kept. */
+int lanczos_synth_random_symmetric_rows(int64_t n, int per_row, uint64_t seed, int64_t row_begin, int64_t row_end,
+                                        Mat_Crs *out) {
     if (!out || n < 1 || n > INT32_MAX || per_row < 0) return 1;
+    if (row_begin < 0 || row_end > n || row_begin >= row_end) return 1;
     memset(out, 0, sizeof *out);
     const uint64_t key = mix64(seed);
-    const size_t draws = (size_t)n * (size_t)per_row;
+    const int64_t rows = row_end - row_begin;
     /* pass 1: count both orientations of every off-diagonal draw */
-    int64_t *cnt = (int64_t *)calloc((size_t)n + 1, sizeof(int64_t));
+    int64_t *cnt = (int64_t *)calloc((size_t)rows + 1, sizeof(int64_t));
     if (!cnt) return 1;
     for (int64_t i = 0; i < n; i++)
         for (int t = 0; t < per_row; t++) {
             const int64_t j = (int64_t)(mix64(key ^ (uint64_t)(2 * (i * per_row + t))) % (uint64_t)n);
             if (j == i) continue;
-            cnt[i + 1]++;
-            cnt[j + 1]++;
+            if (i >= row_begin && i < row_end) cnt[i - row_begin + 1]++;
+            if (j >= row_begin && j < row_end) cnt[j - row_begin + 1]++;
         }
-    for (int64_t i = 0; i < n; i++) cnt[i + 1] += cnt[i];
-    const size_t tot = (size_t)cnt[n];
+    for (int64_t i = 0; i < rows; i++) cnt[i + 1] += cnt[i];
+    const size_t tot = (size_t)cnt[rows];
     ent_t *buf = (ent_t *)malloc(sizeof(ent_t) * (tot ? tot : 1));
-    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)n);
+    int64_t *cur = (int64_t *)malloc(sizeof(int64_t) * (size_t)rows);
     if (!buf || !cur) {
         free(cnt); free(buf); free(cur);
         return 1;
     }
-    memcpy(cur, cnt, sizeof(int64_t) * (size_t)n);
+    memcpy(cur, cnt, sizeof(int64_t) * (size_t)rows);
     for (int64_t i = 0; i < n; i++)
         for (int t = 0; t < per_row; t++) {
             const uint64_t id = (uint64_t)(i * per_row + t);
             const int64_t j = (int64_t)(mix64(key ^ (2 * id)) % (uint64_t)n);
             if (j == i) continue;
+            const int in_i = i >= row_begin && i < row_end, in_j = j >= row_begin && j < row_end;
+            if (!in_i && !in_j) continue;
             const double v = (double)(mix64(key ^ (2 * id + 1)) >> 11) / 4503599627370496.0 - 1.0;
             ent_t a = {(int32_t)i, (int32_t)j, v}, b = {(int32_t)j, (int32_t)i, v};
-            buf[cur[i]++] = a;
-            buf[cur[j]++] = b;
+            if (in_i) buf[cur[i - row_begin]++] = a;
+            if (in_j) buf[cur[j - row_begin]++] = b;
         }
-    (void)draws;
     /* per row: sort by column (insertion sort, rows are short), drop repeats of a
      * column keeping the first (both orientations see the same winner only if
      * the order is orientation independent, so order ties by value bits) */
-    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    int64_t *head = (int64_t *)malloc(sizeof(int64_t) * (size_t)(rows + 1));
     if (!head) { free(cnt); free(buf); free(cur); return 1; }
     head[0] = 0;
 #pragma omp parallel for schedule(dynamic, 4096)
-    for (int64_t i = 0; i < n; i++) {
+    for (int64_t i = 0; i < rows; i++) {
         ent_t *row = buf + cnt[i];
         const int64_t m = cnt[i + 1] - cnt[i];
         for (int64_t a = 1; a < m; a++) {
@@ -166,17 +173,18 @@ int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Cr
             if (a == 0 || row[a].c != row[a - 1].c) uniq++;
         head[i + 1] = uniq + 1; /* + diagonal */
     }
-    for (int64_t i = 0; i < n; i++) head[i + 1] += head[i];
+    for (int64_t i = 0; i < rows; i++) head[i + 1] += head[i];
     out->row_head_indexes = head;
-    if (alloc_crs(out, (size_t)n, (size_t)head[n])) { free(cnt); free(buf); free(cur); return 1; }
+    if (alloc_crs(out, (size_t)rows, (size_t)head[rows])) { free(cnt); free(buf); free(cur); return 1; }
 #pragma omp parallel for schedule(dynamic, 4096)
-    for (int64_t i = 0; i < n; i++) {
-        const ent_t *row = buf + cnt[i];
-        const int64_t m = cnt[i + 1] - cnt[i];
+    for (int64_t r = 0; r < rows; r++) {
+        const int64_t i = row_begin + r;
+        const ent_t *row = buf + cnt[r];
+        const int64_t m = cnt[r + 1] - cnt[r];
         double absum = 0.0;
         for (int64_t a = 0; a < m; a++)
             if (a == 0 || row[a].c != row[a - 1].c) absum += fabs(row[a].v);
-        int64_t p = head[i];
+        int64_t p = head[r];
         int placed = 0;
         for (int64_t a = 0; a < m; a++) {
             if (a > 0 && row[a].c == row[a - 1].c) continue;
@@ -197,4 +205,8 @@ int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Cr
     free(buf);
     free(cur);
     return 0;
+}
+
+int lanczos_synth_random_symmetric(int64_t n, int per_row, uint64_t seed, Mat_Crs *out) {
+    return lanczos_synth_random_symmetric_rows(n, per_row, seed, 0, n, out);
 }

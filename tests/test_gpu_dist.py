@@ -135,6 +135,26 @@ def test_bench_distributed_code_path_with_one_rank(gpu):
     assert np.max(np.abs(np.array(out["ritz_lowest4"]) - want) / want) < 1e-10
 
 
+def test_bench_gpus_flag_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus N` with no launcher around it starts the ranks itself (a child
+    torch.distributed.run, before this process touches the GPU) and relays rank 0's line; rehearsed
+    with one rank, the most a one-GPU box can hold."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--force-dist", "--workload", "lap64", "--steps", "20",
+                        "--warmup", "2", "--big-grid", "0", "--rand-rows", "100000", "--converge-steps", "0"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = p.stdout.strip().splitlines()
+    assert len(lines) == 1, lines                      # the one JSON line and nothing else
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["value"] > 0
+    assert out["config"]["parallelism"] == "row-partition x1"
+    assert out["random_symmetric"]["iters_per_s"] > 0
+
+
 def test_caller_owned_basis_is_validated(gpu):
     """options.basis: leading dimension and column numbering are checked before anything is launched."""
     import torch

@@ -584,18 +584,64 @@ def test_dropin_matches_oracle_and_prints_reference_lines(gpu):
                                                             "reorthogonalization", "wall"}
 
 
+def _exit_margin(o, nth, thr):
+    """How clearly the oracle's run decides its Ritz-convergence exit (src/lanczos.c:120-126): the
+    smallest factor by which any comparison of the run sits away from the threshold (> 1: no
+    comparison is within that factor of flipping)."""
+    margin = np.inf
+    prev = np.zeros(nth)
+    for k in range(o.steps):
+        cnt = min(k + 1, nth)
+        d = np.abs(o.ritz_hist[k][:cnt] - prev[:cnt])
+        worst = d.max()                       # the step exits iff worst <= thr
+        margin = min(margin, worst / thr if worst > thr else thr / max(worst, 1e-300))
+        prev = o.ritz_hist[k].copy()
+    return margin
+
+
 def test_dropin_convergence_exits_follow_the_cpu_rule(gpu):
+    """Exit kind, exit iteration and the exit line equal the CPU rule's (src/lanczos.c:120-133, 185-188)
+    wherever the oracle's run decides with a clear margin; knife-edge thresholds compare values only."""
     a = la.synth_laplacian(1, 2000)
     v0 = la.gaussian_fill(123456789, 0, a.dimension)
-    for thr in (10e-5, 1e-2):
+    clear = 0
+    for thr in (10e-5, 1e-2, 3e-4, 2e-3):
         o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 2, 400, thr)
-        res, out, _ = run_dropin(a, 2, 400, thr, env={"LANCZOS_HIP_QUIET": "1"})
+        res, out, err = run_dropin(a, 2, 400, thr, env={"LANCZOS_HIP_JSON": "1"})
+        rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
         assert res["rc"] == 0
-        if o.exit_kind == 1:
-            assert "converged " in out
-        # same exit step => same values to parity tolerance; the exit step itself may differ by
-        # one where a difference sits within rounding of the threshold, so compare to it loosely
-        assert rel_err(res["eig"], o.eigenvalues) < 1e-6
+        assert o.exit_kind == 1                      # these runs end on standing Ritz values
+        if _exit_margin(o, 2, thr) > 1.01:           # a 1 % margin is ~1e10 times the parity tolerance
+            clear += 1
+            assert rec["exit_kind"] == 1 and rec["exit_step"] == o.steps, (thr, rec, o.steps)
+            step_lines = [ln for ln in out.splitlines() if ln[:1].isdigit() and "\t" in ln]
+            assert len(step_lines) == o.steps - 1    # the exit step prints "converged", not its values
+            diffs = o.ritz_hist[o.steps - 2] - o.ritz_hist[o.steps - 1]
+            conv = [ln for ln in out.splitlines() if ln.startswith("converged ")]
+            assert len(conv) == 1
+            got = [float(x) for x in conv[0].split()[1:]]
+            assert len(got) == 2 and np.allclose(got, diffs, rtol=0.06, atol=0)   # printed at %.1E
+            assert "Reached max iterations" not in out
+            assert rel_err(res["eig"], o.eigenvalues) < 1e-10
+        else:
+            assert rel_err(res["eig"], o.eigenvalues) < 1e-6
+    assert clear >= 3
+    # beta exit: a matrix with five distinct eigenvalues spans its Krylov space in five steps
+    n = 1000
+    d = np.repeat([1.0, 2.5, 4.0, 7.0, 11.0], n // 5)
+    diag = la.CrsMatrix(d, np.arange(n, dtype=np.int64), np.arange(n + 1, dtype=np.int64))
+    v0 = la.gaussian_fill(123456789, 0, n)
+    o = oracle.lanczos_crs(diag.row_head_indexes, diag.column_index, diag.values, v0, 2, 50, 1e-6)
+    res, out, err = run_dropin(diag, 2, 50, 1e-6, env={"LANCZOS_HIP_JSON": "1"})
+    rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
+    assert o.exit_kind == 2 and o.steps == 5
+    assert res["rc"] == 0 and rec["exit_kind"] == 2 and rec["exit_step"] == 5
+    assert [ln for ln in out.splitlines() if ln.endswith("beta converged")] == ["0.0000000 beta converged"]
+    assert rel_err(res["eig"], o.eigenvalues) < 1e-10
+    # max-iter exit
+    res, out, err = run_dropin(a, 2, 30, 0.0, env={"LANCZOS_HIP_JSON": "1"})
+    rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
+    assert rec["exit_kind"] == 0 and rec["exit_step"] == 29 and "Reached max iterations (30)" in out
     # bad arguments: EXIT_FAILURE and the reference's message (src/lanczos_cuda.c:324-327)
     res, out, _ = run_dropin(a, 2, 1, 0.0)
     assert res["rc"] == 1 and "max_iter must be >= 2" in out
@@ -682,10 +728,13 @@ def test_dropin_checkpoints_and_resumes(gpu, tmp_path, reorth):
     assert os.path.exists(ck) and not os.path.exists(ck + ".tmp")
     resumed, out_res, err_res = run_dropin(a, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=ck))
     assert resumed["rc"] == 0 and resumed["eig"] == whole["eig"]
-    saved = int([ln for ln in err_res.splitlines() if ln.startswith("[INIT] name=resumed")][0].split("=")[-1])
-    assert 60 <= saved <= 70
+    line = [ln for ln in err_res.splitlines() if ln.startswith("[INIT] name=resumed")][0]
+    saved = int(line.split("iterations=")[1].split()[0])
+    printed = int(line.split("printed=")[1].split()[0])
+    assert 60 <= saved <= 70 and printed == 60       # the last checkpoint was written after line 60
+    # every line the interrupted run had not printed when it wrote the file comes out now
     its = [int(ln.split("\t")[0]) for ln in out_res.splitlines() if ln[:1].isdigit() and "\t" in ln]
-    assert its == list(range(saved + 1, 101))
+    assert its == list(range(printed + 1, 101))
     info = json.loads([ln for ln in err_res.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
     assert info["iterations"] == 100
     # a file that is no checkpoint is refused
@@ -693,3 +742,20 @@ def test_dropin_checkpoints_and_resumes(gpu, tmp_path, reorth):
     open(bad, "wb").write(b"not a checkpoint")
     res_bad, _, _ = run_dropin(a, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=bad))
     assert res_bad["rc"] != 0
+    if reorth == "full":
+        # a checkpoint of another matrix of the same size and mode is refused, not continued
+        other = la.CrsMatrix(a.values * 1.5, a.column_index, a.row_head_indexes)
+        res_o, out_o, _ = run_dropin(other, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=ck))
+        assert res_o["rc"] != 0 and "another matrix" in out_o
+        # damaged header fields (counts that would become loop bounds and buffer sizes) are refused
+        raw = bytearray(open(ck, "rb").read())
+        import struct
+        # layout: magic[8], n, ldv, nnz (int64), fingerprint (uint64), then int32 fields:
+        # reorth, max_iter, nvec, k, lazy, lazy_flushed_k, alpha_count, norm_count, ...
+        base_off = 8 + 4 * 8
+        for field, value in ((3, -5), (6, 1 << 20), (7, -1)):
+            hurt = bytearray(raw)
+            struct.pack_into("<i", hurt, base_off + 4 * field, value)
+            open(bad, "wb").write(bytes(hurt))
+            res_h, out_h, _ = run_dropin(a, 4, 101, 0.0, env=dict(base, LANCZOS_HIP_RESUME=bad))
+            assert res_h["rc"] != 0, (field, value)

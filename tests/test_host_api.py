@@ -289,3 +289,28 @@ def test_matrix_market_reader_against_scipy(tmp_path):
         open(path, "w").write(bad)
         with pytest.raises(ValueError):
             la.read_matrix_market(path)
+
+
+def test_bench_builds_the_launch_line_for_several_gpus():
+    """bench.py --gpus N without WORLD_SIZE starts `python -m torch.distributed.run` itself."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    cmd = bench.launch_command(["--gpus", "8", "--steps", "20", "--warmup", "3"], 8, 29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+
+
+def test_random_symmetric_rows_are_the_rows_of_the_whole_matrix():
+    a = la.synth_random_symmetric(5000, 10, 42)
+    h = a.row_head_indexes
+    for r0, r1 in ((0, 5000), (0, 1234), (1234, 4000), (4000, 5000)):
+        s = la.synth_random_symmetric_rows(5000, 10, 42, r0, r1)
+        assert np.array_equal(s.row_head_indexes, h[r0:r1 + 1] - h[r0])
+        assert np.array_equal(s.column_index, a.column_index[h[r0]:h[r1]])
+        assert np.array_equal(s.values, a.values[h[r0]:h[r1]])
