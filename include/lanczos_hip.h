@@ -102,6 +102,20 @@ typedef struct crs {
 int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
                     int nth_eig, int max_iter, double threshold);
 
+/*
+ * The same solver for an operator that exists only as a host function: the reference's plugin
+ * contract (src/lanczos.h:5, call site src/lanczos.c:110), where any
+ *     void matvec(const void *mat, const double *vec, double *dist)
+ * that overwrites dist[0..dimension) with A vec can be iterated on.  The Lanczos vectors, the
+ * recurrence, the reorthogonalisation against the basis and the norms stay on the GPU; per
+ * iteration the current vector goes to the host, `matvec` is called once on host memory exactly
+ * as src/lanczos.c:110 calls it, and the product goes back.  Arguments, termination rules, output
+ * lines, return codes and environment knobs are those of lanczos_hip_crs.
+ */
+typedef void lanczos_hip_matvec_fn(const void *mat, const double *vec, double *dist);
+int lanczos_hip_operator(lanczos_hip_matvec_fn *matvec, const void *mat, size_t dimension, double eigenvalues[],
+                         double *eigenvectors[], int nth_eig, int max_iter, double threshold);
+
 /* ------------------------------------------------------------------------ */
 /* Engine handle API (what lanczos_hip_crs is built from; used by tests and  */
 /* benchmarks, and by multi-GPU hosts that interleave collectives)           */
@@ -134,7 +148,7 @@ enum {
     LANCZOS_HIP_SPMV_PIPE = 3,   /* stream form, software pipelined across row groups */
     LANCZOS_HIP_SPMV_PIPE_NT = 4, /* pipe form with non-temporal col/val loads */
     LANCZOS_HIP_SPMV_ROWS = 5,   /* pipe form whose gathers run row-wise (coalesced for stencil-like
-                                    matrices); needs every 64-row group to hold <= 512 entries */
+                                    matrices); needs every 64-row group to hold <= 481 entries */
     LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
                                     caches (random sparsity): entries regrouped on the device by
                                     (block of 4096 rows, column panel of 2^18 columns); a workgroup keeps
@@ -255,6 +269,10 @@ void lanczos_hip_gaussian_fill(uint64_t seed, int64_t row_begin, int64_t n, doub
  * (3-vector mode: max(max_iter, 65536) per run, the length of the alpha/beta history).
  */
 int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out);
+
+/* From now on the engine's product is the caller's host function (see lanczos_hip_operator) instead
+ * of the uploaded matrix, which may be empty (nnz = 0).  Single-GPU engines. */
+int lanczos_hip_set_operator(lanczos_hip_engine *e, lanczos_hip_matvec_fn *matvec, const void *mat);
 
 /* Number of iterations completed since the last set_start. */
 int lanczos_hip_iterations(const lanczos_hip_engine *e);

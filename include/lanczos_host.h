@@ -66,9 +66,9 @@ typedef struct mat_matvec {
  * (message on stderr + exit(EXIT_FAILURE) for NULL / out-of-range arguments),
  * but the iteration runs on the GPU: a Mat_Crs operator (matvec == matvec_crs)
  * goes to lanczos_hip_crs() as it is, a Mat_Coo operator (matvec == matvec_coo)
- * is first converted with convert_from_coo(mat, 0).  Any other plugin has no
- * device form and is refused with a message and exit(EXIT_FAILURE): there is
- * no CPU path behind this entry.
+ * is first converted with convert_from_coo(mat, 0).  Any other plugin goes to
+ * lanczos_hip_operator(): the function is called on host memory once per iteration, as
+ * src/lanczos.c:110 calls it, and everything else of the iteration runs on the GPU.
  */
 void lanczos(const Mat_Matvec mat_matvec, double eigenvalues[], double *eigenvectors[],
              int nth_eig, int max_iter, double threshold);

@@ -168,6 +168,19 @@ _host.lanczos_synth_random_symmetric_rows.argtypes = [C.c_int64, C.c_int, C.c_ui
 _host.lanczos_synth_random_symmetric_rows.restype = C.c_int
 _host.lanczos_free_crs.argtypes = [C.POINTER(Mat_Crs)]
 _host.lanczos_free_crs.restype = None
+MATVEC_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)   # Matvec_General (reference src/lanczos.h:5)
+
+
+class Mat_Matvec(C.Structure):
+    _fields_ = [("mat", C.c_void_p), ("matvec", MATVEC_FN), ("dimension", C.c_size_t)]
+
+
+_host.lanczos.argtypes = [Mat_Matvec, _dp, C.c_void_p, C.c_int, C.c_int, C.c_double]
+_host.lanczos.restype = None
+_hip.lanczos_hip_operator.argtypes = [MATVEC_FN, C.c_void_p, C.c_size_t, _dp, C.c_void_p, C.c_int, C.c_int, C.c_double]
+_hip.lanczos_hip_operator.restype = C.c_int
+_hip.lanczos_hip_set_operator.argtypes = [C.c_void_p, MATVEC_FN, C.c_void_p]
+_hip.lanczos_hip_set_operator.restype = C.c_int
 _libc = C.CDLL(None)
 _libc.free.argtypes = [C.c_void_p]
 
@@ -341,6 +354,22 @@ def lanczos_hip_crs(a: CrsMatrix, nth_eig: int, max_iter: int, threshold: float,
         else:
             os.environ["LANCZOS_HIP_EIGENVECTORS"] = old
     return rc, eig[:max(nth_eig, 0)], y[:max(nth_eig, 0)]
+
+
+def lanczos_plugin(apply, dimension: int, nth_eig: int, max_iter: int, threshold: float) -> np.ndarray:
+    """lanczos() of the host library (reference src/lanczos.h:34-36) with a custom Matvec_General:
+    `apply(x) -> y` is wrapped into the plugin's C signature and called on host memory once per
+    iteration.  Exits the process on failure, as the reference's lanczos() does."""
+    def cb(_mat, vec, dist):
+        x = np.ctypeslib.as_array(vec, (dimension,))
+        np.ctypeslib.as_array(dist, (dimension,))[:] = apply(x)
+
+    fn = MATVEC_FN(cb)
+    token = C.c_int(0)   # the reference's lanczos() refuses a NULL mat pointer
+    eig = np.zeros(nth_eig)
+    _host.lanczos(Mat_Matvec(C.cast(C.pointer(token), C.c_void_p), fn, dimension), eig.ctypes.data_as(_dp), None,
+                  nth_eig, max_iter, threshold)
+    return eig
 
 
 BLOCK_WIDTH = 16
@@ -633,6 +662,10 @@ class Engine:
     def spmv_noalloc(self, x_dev: int, y_dev: int, dot_dev: int | None = None):
         """y = A x on device addresses (enqueued on the engine's stream), no allocation."""
         _check(_hip.lanczos_hip_spmv_noalloc(self._h, x_dev, y_dev, dot_dev), "lanczos_hip_spmv_noalloc")
+
+    def set_operator(self, fn, mat_ptr=None):
+        """fn: a MATVEC_FN instance (keep it alive as long as the engine runs)."""
+        _check(_hip.lanczos_hip_set_operator(self._h, fn, mat_ptr), "lanczos_hip_set_operator")
 
     def get_vector(self, k: int):
         out = np.empty(self.n)

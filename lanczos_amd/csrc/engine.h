@@ -84,6 +84,13 @@ struct Engine {
     int32_t *d_dlen = nullptr, *d_doff = nullptr;  // [patterns], [patterns][dict_stride]
     double *d_dval = nullptr;
     int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
+    // operator supplied by the caller as a host function (the reference's Matvec_General plugin,
+    // src/lanczos.h:5): the product goes through two pinned host vectors, everything else stays here
+    lanczos_hip_matvec_fn *ext_matvec = nullptr;
+    const void *ext_mat = nullptr;
+    double *h_ext_x = nullptr, *h_ext_w = nullptr;
+    int set_operator(lanczos_hip_matvec_fn *fn, const void *mat);
+    int launch_product(int kk);  // w = A v_kk into slot kk + 1 and the partials of v_kk . w
     // iteration state
     int k = 0;
     bool started = false;

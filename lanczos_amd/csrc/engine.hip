@@ -208,8 +208,9 @@ int Engine::setup_device(const lanczos_hip_options &opt, int64_t n_, int64_t n_e
         own_stream = true;
     }
     rp64 = nnz >= ((int64_t)1 << 31);
-    HIP_TRY(hipMalloc(&d_val, sizeof(double) * std::max<int64_t>(nnz, 1)));
-    HIP_TRY(hipMalloc(&d_col, sizeof(int32_t) * std::max<int64_t>(nnz, 1)));
+    // a few entries of padding: the rows SpMV loads aligned granules of four entries
+    HIP_TRY(hipMalloc(&d_val, sizeof(double) * (std::max<int64_t>(nnz, 1) + 8)));
+    HIP_TRY(hipMalloc(&d_col, sizeof(int32_t) * (std::max<int64_t>(nnz, 1) + 8)));
     HIP_TRY(hipMalloc(&d_rp, (rp64 ? 8 : 4) * (n + 1)));
     return 0;
 }
@@ -294,9 +295,9 @@ int Engine::choose_spmv(int requested) {
     HIP_TRY(hipStreamSynchronize(stream));
     HIP_TRY(hipFree(d_stats));
     const int64_t max_span = (int64_t)stats[0];
-    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kTile)
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kRowsMaxSpan)
         return fail("lanczos_hip_create: the rows SpMV needs every 64-row group to hold <= %d entries (max %lld)",
-                    kTile, (long long)max_span);
+                    kRowsMaxSpan, (long long)max_span);
     if (const char *s = getenv("LANCZOS_HIP_PANEL_BITS"))
         if (atoi(s) >= 10 && atoi(s) <= 24) panel_bits = atoi(s);
     const bool no_dict = getenv("LANCZOS_HIP_NO_DICT") && atoi(getenv("LANCZOS_HIP_NO_DICT")) != 0;
@@ -313,7 +314,7 @@ int Engine::choose_spmv(int requested) {
     }
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO) {
         spmv_kind = LANCZOS_HIP_SPMV_PIPE;
-        if (max_span <= kTile && stats[1] > 0 && 2 * stats[2] > stats[1]) {
+        if (max_span <= kRowsMaxSpan && stats[1] > 0 && 2 * stats[2] > stats[1]) {
             spmv_kind = LANCZOS_HIP_SPMV_ROWS;
         } else {
             // rows that reach across more of x than the L2s hold (the sampled rows' mean column
@@ -447,6 +448,8 @@ Engine::~Engine() {
     (void)hipFree(d_scal);
     (void)hipFree(d_alpha);
     (void)hipFree(d_beta);
+    if (h_ext_x) (void)hipHostFree(h_ext_x);
+    if (h_ext_w) (void)hipHostFree(h_ext_w);
     if (h_hist) (void)hipHostFree(h_hist);
     if (h_sel) (void)hipHostFree(h_sel);
     if (sel_event) (void)hipEventDestroy(sel_event);
@@ -498,9 +501,12 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, do
     if (e->spmv_kind == LANCZOS_HIP_SPMV_ROWS) {
         const int64_t groups = (rows + 63) / 64;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
-        int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
+        // two workgroups per CU: the kernel saturates the memory pipeline with 8 wavefronts per CU, and
+        // fewer, longer-running wavefronts spend less of their life in the pipeline's prologue (measured
+        // 0.363 ms against 0.370 ms with eight workgroups per CU on the 256^3 Laplacian)
+        int blocks = (int)std::min<int64_t>(e->cus * 2 / 8 * 8, round_up(chunks, 8));
         *nparts = blocks;
-        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, rp, e->d_col,
+        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp, e->d_col,
                            e->d_val, x, xdot, y, parts);
         return;
     }
@@ -900,12 +906,41 @@ int Engine::flush_lazy() {
     return 0;
 }
 
+// The caller's operator: v_k to the host, the plugin, the product back; the alpha partials are
+// then those of a plain dot product.  The stream is waited on once per product.
+int Engine::set_operator(lanczos_hip_matvec_fn *fn, const void *mat) {
+    if (!fn) return fail("lanczos_hip_set_operator: NULL function");
+    if (slab) return fail("lanczos_hip_set_operator: not available on a row-partitioned engine");
+    HIP_TRY(hipSetDevice(device));
+    if (!h_ext_x) HIP_TRY(hipHostMalloc((void **)&h_ext_x, sizeof(double) * (size_t)n, hipHostMallocDefault));
+    if (!h_ext_w) HIP_TRY(hipHostMalloc((void **)&h_ext_w, sizeof(double) * (size_t)n, hipHostMallocDefault));
+    ext_matvec = fn;
+    ext_mat = mat;
+    snprintf(spmv_name, sizeof(spmv_name), "host_operator");
+    return 0;
+}
+
+int Engine::launch_product(int kk) {
+    if (!ext_matvec) return launch_spmv(vec(kk), vec(kk), vec(kk + 1), &alpha_count);
+    HIP_TRY(hipMemcpyAsync(h_ext_x, vec(kk), sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    ext_matvec(ext_mat, h_ext_x, h_ext_w);  // overwrites all of dist, as both reference operators do
+    HIP_TRY(hipMemcpyAsync(vec(kk + 1), h_ext_w, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, stream));
+    const int blocks = vec_blocks();
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, 32.0 * (double)n);
+    hipLaunchKernelGGL(k_dot, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)vec(kk),
+                       (const double2 *)vec(kk + 1), npad / 2, d_partials);
+    alpha_count = blocks;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 // One whole iteration on a single GPU: the reductions' last stages are folded
 // into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
     if (int rc = check_can_step()) return rc;
     if (spec_spmv_k != k)  // else: launched ahead by the previous iteration, on the vector that stood
-        if (int rc = launch_spmv(vec(k), vec(k), vec(k + 1), &alpha_count)) return rc;
+        if (int rc = launch_product(k)) return rc;
     spec_spmv_k = -1;
     if (lazy) {
         const int blocks = vec_blocks();
@@ -981,7 +1016,7 @@ int Engine::selective_lazy_tail() {
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sel_event, stream));
-    if (k + 2 < nvec && k + 1 < hist_cap && k + 1 < max_iter - 1) {
+    if (!ext_matvec && k + 2 < nvec && k + 1 < hist_cap && k + 1 < max_iter - 1) {
         if (int rc = launch_spmv(vec(k + 1), vec(k + 1), vec(k + 2), &alpha_count)) return rc;
         spec_spmv_k = k + 1;
     }
@@ -1150,6 +1185,11 @@ int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double 
     if (!e) return lz::fail("lanczos_hip_run: NULL engine");
     if (E(e)->slab) return lz::fail("lanczos_hip_run: row-partitioned engines are driven phase by phase");
     return E(e)->run(steps, alpha_out, beta_out);
+}
+
+int lanczos_hip_set_operator(lanczos_hip_engine *e, lanczos_hip_matvec_fn *matvec, const void *mat) {
+    if (!e) return lz::fail("lanczos_hip_set_operator: NULL engine");
+    return E(e)->set_operator(matvec, mat);
 }
 
 int lanczos_hip_iterations(const lanczos_hip_engine *e) { return e ? E(e)->k : 0; }

@@ -41,17 +41,18 @@ int env_reorth() {
     return -1;
 }
 
-}  // namespace
-
-extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[], int nth_eig,
-                               int max_iter, double threshold) {
+// The solver behind both entry points: `mat` is the matrix to upload, or NULL when the operator is
+// the host function `op` (the engine then holds an empty matrix of that dimension).
+int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, size_t dimension, double eigenvalues[],
+          double *eigenvectors[], int nth_eig, int max_iter, double threshold) {
+    const size_t length = mat ? mat->length : 0;
     // Neither reference solver fills `eigenvectors` (src/lanczos.c:20, src/lanczos_cuda.c:284), and the
     // reference's driver passes an uninitialised pointer array (src/main.c:20): it is only written to
     // when LANCZOS_HIP_EIGENVECTORS=1 says that the caller's pointers are real.
     const bool want_vectors = eigenvectors != NULL && env_int("LANCZOS_HIP_EIGENVECTORS", 0) != 0;
-    if (mat == NULL || eigenvalues == NULL) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
-    if (mat->dimension > (size_t)INT_MAX) {                       // src/lanczos_cuda.c:319-322
-        printf("Matrix dimension too large for HIP CRS (dim=%zu)\n", mat->dimension);
+    if ((mat == NULL && op == NULL) || eigenvalues == NULL || dimension == 0) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
+    if (dimension > (size_t)INT_MAX) {                            // src/lanczos_cuda.c:319-322
+        printf("Matrix dimension too large for HIP CRS (dim=%zu)\n", dimension);
         return EXIT_FAILURE;
     }
     if (max_iter < 2) {  // src/lanczos_cuda.c:324-327
@@ -98,13 +99,20 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
     const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
     const char *resume_path = getenv("LANCZOS_HIP_RESUME");
 
-    if (lz::Engine::create(&e, (int64_t)mat->dimension, (int64_t)mat->length, mat->row_head_indexes,
-                           mat->column_index, mat->values, max_iter, &opt) != 0)
-        goto cleanup;
+    if (mat) {
+        if (lz::Engine::create(&e, (int64_t)dimension, (int64_t)length, mat->row_head_indexes, mat->column_index,
+                               mat->values, max_iter, &opt) != 0)
+            goto cleanup;
+    } else {
+        const std::vector<int64_t> no_rows(dimension + 1, 0);
+        if (lz::Engine::create(&e, (int64_t)dimension, 0, no_rows.data(), nullptr, nullptr, max_iter, &opt) != 0)
+            goto cleanup;
+        if (e->set_operator(op, op_mat) != 0) goto cleanup;
+    }
     if (e->enable_host_history() != 0) goto cleanup;
     {
-        std::vector<double> v0(mat->dimension);
-        lanczos_hip_gaussian_fill(seed, 0, (int64_t)mat->dimension, v0.data());
+        std::vector<double> v0(dimension);
+        lanczos_hip_gaussian_fill(seed, 0, (int64_t)dimension, v0.data());
         if (e->set_start(v0.data(), true, 1.0) != 0) goto cleanup;
     }
     if (resume_path && *resume_path) {
@@ -203,7 +211,7 @@ extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double 
         // eigenvectors[i][0..n) = Ritz vector of eigenvalues[i], i < min(nth_eig, steps): one pass over
         // the resident basis per eight vectors
         const int m = std::min(nth_eig, steps_used);
-        const size_t n = mat->dimension;
+        const size_t n = dimension;
         std::vector<double> y((size_t)m * n), ev((size_t)m);
         if (lanczos_hip_ritz_vectors(reinterpret_cast<lanczos_hip_engine *>(e), steps_used, m, ev.data(), y.data(),
                                      NULL) != 0) {
@@ -243,7 +251,22 @@ cleanup:
                 "{\"lanczos_hip\": {\"status\": %d, \"dimension\": %zu, \"nnz\": %zu, \"iterations\": %d, "
                 "\"exit_kind\": %d, \"exit_step\": %d, \"reorth_steps\": %d, \"spmv_kernel\": \"%s\", \"sec\": {\"init\": %.6f, \"spmv\": %.6f, "
                 "\"diagonalization\": %.6f, \"reorthogonalization\": %.6f, \"wall\": %.6f}}}\n",
-                status, mat->dimension, mat->length, iterations, exit_kind, steps_used, reorth_steps, kernel_name, time_init, t_spmv,
+                status, dimension, length, iterations, exit_kind, steps_used, reorth_steps, kernel_name, time_init, t_spmv,
                 time_diag, t_reorth, wall);
     return status;
+}
+
+}  // namespace
+
+extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[], int nth_eig,
+                               int max_iter, double threshold) {
+    if (mat == NULL) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
+    return solve(mat, nullptr, nullptr, mat->dimension, eigenvalues, eigenvectors, nth_eig, max_iter, threshold);
+}
+
+extern "C" int lanczos_hip_operator(lanczos_hip_matvec_fn *matvec, const void *mat, size_t dimension,
+                                    double eigenvalues[], double *eigenvectors[], int nth_eig, int max_iter,
+                                    double threshold) {
+    if (matvec == NULL) return EXIT_FAILURE;
+    return solve(nullptr, matvec, mat, dimension, eigenvalues, eigenvectors, nth_eig, max_iter, threshold);
 }

@@ -19,6 +19,7 @@ constexpr int kWavesPerBlock = 4;
 // with the non-temporal hint: on MI355X a pure read stream runs ~14 % faster with
 // it (7.0 vs 6.2 TB/s measured on k_dots) because it does not churn L2/MALL.
 typedef double d2v __attribute__((ext_vector_type(2)));
+typedef int i4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double2 ld_stream(const double2 *p) {
     const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
     return make_double2(t.x, t.y);
@@ -561,18 +562,21 @@ k_merge_fixup(int64_t count, const int *__restrict__ carry_row, const double *__
 // coalesced load costs.  Each lane sums its row left to right (the order of
 // src/crs.c:172-175) and no product is staged in LDS.
 //
-// Used when every 64-row group's span fits one tile (checked on the host);
-// rows longer than kRowChunk entries loop over chunks.
+// Used when every 64-row group's span, counted from the multiple of four entries below its
+// start, fits one tile (checked on the host: span <= kRowsMaxSpan); rows longer than kRowChunk
+// entries loop over chunks.
 constexpr int kRowChunk = 8;
+constexpr int kRowsAlignC = 32, kRowsAlignV = 16;  // entries per 128-byte line of col / val
+constexpr int kRowsMaxSpan = kTile - (kRowsAlignC - 1);
 
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
-k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__restrict__ col,
             const double *__restrict__ val, const double *__restrict__ x,
             const double *__restrict__ xdot, double *__restrict__ y,
             double *__restrict__ partials) {
-    __shared__ double lds_v[kWavesPerBlock][kTile];
-    __shared__ int32_t lds_c[kWavesPerBlock][kTile];
+    __shared__ __align__(16) double lds_v[kWavesPerBlock][kTile];
+    __shared__ __align__(16) int32_t lds_c[kWavesPerBlock][kTile];
     __shared__ double red[kWavesPerBlock];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -589,6 +593,8 @@ k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
     double *myv = lds_v[wave];
     int32_t *myc = lds_c[wave];
     double acc = 0.0;
+    // the last aligned granules that still start inside the arrays (both are padded by the host)
+    const RP last4 = (RP)((nnz - 1) & ~(int64_t)3), last2 = (RP)((nnz - 1) & ~(int64_t)1);
 
     auto row_of = [&](int64_t i) -> int64_t {
         const int64_t r = (((c0 + i * slots) * kWavesPerBlock + wave) << 6) + lane;
@@ -598,35 +604,40 @@ k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
         lo = rp[r];
         hi = rp[r < n ? r + 1 : n];
     };
-    auto issue_colval = [&](RP s_lo, RP s_hi, int32_t (&cj)[kTileU], double (&vj)[kTileU]) {
-        const RP last = s_hi > s_lo ? s_hi - 1 : (s_lo > 0 ? s_lo - 1 : 0);
+    // The tile of a group starts at its span rounded down to a multiple of four entries, so that
+    // every lane loads 16 bytes at a time: two loads of four column indices, four of two values
+    // (6 memory instructions per tile where loads of single entries take 16).  Granules past the end
+    // of the arrays are clamped to the last one; no row reads those tile slots.
+    auto issue_colval = [&](RP s_lo, i4v (&cj)[2], d2v (&vj)[4]) {
+        const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
 #pragma unroll
-        for (int u = 0; u < kTileU; ++u) {
-            RP j = s_lo + u * 64 + lane;
-            j = j < last ? j : last;
-            cj[u] = col[j];
+        for (int u = 0; u < 2; ++u) {
+            RP j = ac + u * 256 + 4 * lane;
+            j = j < last4 ? j : last4;
+            cj[u] = *reinterpret_cast<const i4v *>(col + j);
         }
 #pragma unroll
-        for (int u = 0; u < kTileU; ++u) {
-            RP j = s_lo + u * 64 + lane;
-            j = j < last ? j : last;
-            vj[u] = val[j];
+        for (int u = 0; u < 4; ++u) {
+            RP j = av + u * 128 + 2 * lane;
+            j = j < last2 ? j : last2;
+            vj[u] = *reinterpret_cast<const d2v *>(val + j);
         }
     };
-    auto step = [&](int64_t i, int32_t (&c_c)[kTileU], double (&v_c)[kTileU], int32_t (&c_n)[kTileU],
-                    double (&v_n)[kTileU], RP &lo_c, RP &hi_c, const RP &lo_n, const RP &hi_n) {
+    auto step = [&](int64_t i, i4v (&c_c)[2], d2v (&v_c)[4], i4v (&c_n)[2], d2v (&v_n)[4], RP &lo_c,
+                    RP &hi_c, const RP &lo_n, const RP &hi_n) {
         const int64_t row = row_of(i);
         const RP my_lo = lo_c, my_hi = hi_c;
         const RP span_lo = __shfl(my_lo, 0);
-        const int off = (int)(my_lo - span_lo);   // this row's first entry inside the tile
+        // this row's first entry inside the two tiles
+        const int off = (int)(my_lo - (span_lo & ~(RP)(kRowsAlignC - 1)));
+        const int offv = (int)(my_lo - (span_lo & ~(RP)(kRowsAlignV - 1)));
         const int len = (int)(my_hi - my_lo);
         const int32_t safe_col = (int32_t)(row < n ? row : n - 1);
         // (a) park this group's tile in LDS
 #pragma unroll
-        for (int u = 0; u < kTileU; ++u) {
-            myc[u * 64 + lane] = c_c[u];
-            myv[u * 64 + lane] = v_c[u];
-        }
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<i4v *>(myc + u * 256 + 4 * lane) = c_c[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) *reinterpret_cast<d2v *>(myv + u * 128 + 2 * lane) = v_c[u];
         __builtin_amdgcn_wave_barrier();
         // (b) row-wise gathers of the first chunk
         int32_t cr[kRowChunk];
@@ -638,12 +649,12 @@ k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
         const double xd = xdot[row < n ? row : n - 1];
         // (c) offsets of group i+2, col/val of group i+1 (behind the gathers in the queue)
         offsets(row_of(i + 2 < count ? i + 2 : count - 1), lo_c, hi_c);
-        issue_colval(__shfl(lo_n, 0), __shfl(hi_n, 63), c_n, v_n);
+        issue_colval(__shfl(lo_n, 0), c_n, v_n);
         // (d) the row sum, left to right
         double sum = 0.0;
 #pragma unroll
         for (int j = 0; j < kRowChunk; ++j) {
-            const double v = j < len ? myv[off + j] : 0.0;
+            const double v = j < len ? myv[offv + j] : 0.0;
             sum += v * xr[j];
         }
         // rows longer than one chunk (wave-uniform trip count)
@@ -657,7 +668,7 @@ k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
 #pragma unroll
             for (int j = 0; j < kRowChunk; ++j) {
                 const bool in = j0 + j < len;
-                const double v = in ? myv[off + j0 + j] : 0.0;
+                const double v = in ? myv[offv + j0 + j] : 0.0;
                 const int32_t c = in ? myc[off + j0 + j] : safe_col;
                 sum += v * x[c];
             }
@@ -673,9 +684,9 @@ k_spmv_rows(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
         RP loA, hiA, loB, hiB;
         offsets(row_of(0), loA, hiA);
         offsets(row_of(count > 1 ? 1 : 0), loB, hiB);
-        int32_t cA[kTileU], cB[kTileU];
-        double vA[kTileU], vB[kTileU];
-        issue_colval(__shfl(loA, 0), __shfl(hiA, 63), cA, vA);
+        i4v cA[2], cB[2];
+        d2v vA[4], vB[4];
+        issue_colval(__shfl(loA, 0), cA, vA);
         int64_t i = 0;
         for (; i + 1 < count; i += 2) {
             step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);

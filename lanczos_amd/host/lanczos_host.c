@@ -1,7 +1,8 @@
 /*
  * lanczos(): the reference's CPU entry point (src/lanczos.h:34-36) re-pointed
  * at the HIP engine.  Argument checks, messages and exit behaviour follow
- * src/lanczos.c:28-43; the iteration itself is lanczos_hip_crs().
+ * src/lanczos.c:28-43; the iteration itself is lanczos_hip_crs(), or lanczos_hip_operator() for a
+ * plugin that is neither of the reference's two.
  */
 #include <limits.h>
 #include <stdio.h>
@@ -38,9 +39,10 @@ void lanczos(const Mat_Matvec mat_matvec, double eigenvalues[], double *eigenvec
         rc = lanczos_hip_crs(&crs, eigenvalues, eigenvectors, nth_eig, max_iter, threshold);
         lanczos_free_crs(&crs);
     } else {
-        fprintf(stderr, "lanczos: this build runs Mat_Crs and Mat_Coo operators on the HIP engine; "
-                        "a custom Matvec_General has no device form\n");
-        exit(EXIT_FAILURE);
+        /* any other plugin (src/lanczos.h:5): the engine calls it on host memory once per iteration,
+         * as src/lanczos.c:110 does, and keeps the vectors and their arithmetic on the GPU */
+        rc = lanczos_hip_operator(mat_matvec.matvec, mat_matvec.mat, mat_matvec.dimension, eigenvalues, eigenvectors,
+                                  nth_eig, max_iter, threshold);
     }
     if (rc != EXIT_SUCCESS) {
         fprintf(stderr, "lanczos: HIP engine failed: %s\n", lanczos_hip_last_error());

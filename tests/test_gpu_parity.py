@@ -146,7 +146,7 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
     lens[rng.integers(0, n, 50)] = 11
     head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     a = la.CrsMatrix(rng.standard_normal(head[-1]), rng.integers(0, n, head[-1]).astype(np.int64), head)
-    assert int((head[64::64] - head[:-64:64]).max()) <= 512
+    assert int((head[64::64] - head[:-64:64]).max()) <= 481
     x = rng.standard_normal(n)
     want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
     with la.Engine(a, 3, spmv="rows") as e:
@@ -156,6 +156,24 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
     big = irregular_matrix(1000, 3, ((0, 2000),))
     with pytest.raises(la.LanczosHipError, match="rows SpMV needs"):
         la.Engine(big, 3, spmv="rows")
+    # groups at the limit (481 entries from any alignment of their first entry) and the array ends:
+    # the kernel's tiles start on 128-byte lines and the 16-byte granules past the last entry are clamped
+    for tail in (0, 1, 2, 3):
+        targets = [481, 478 + tail, 481, 479, 481, 481]
+        lens = []
+        for t in targets:
+            g = np.full(64, 7)
+            extra = rng.integers(0, 64, t - 448)
+            np.add.at(g, extra, 1)
+            lens.append(g)
+        lens = np.concatenate(lens)[:64 * len(targets) - 5 * tail]     # n not a multiple of 64
+        n2 = lens.size
+        head = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        b = la.CrsMatrix(rng.standard_normal(head[-1]), rng.integers(0, n2, head[-1]).astype(np.int64), head)
+        x2 = rng.standard_normal(n2)
+        want2 = oracle.matvec_crs(b.row_head_indexes, b.column_index, b.values, x2)
+        with la.Engine(b, 3, spmv="rows") as e:
+            assert np.all(np.abs(e.spmv(x2) - want2) <= spmv_tolerance(b, x2)), tail
 
 
 def test_dictionary_spmv_on_repeating_rows(gpu):
@@ -645,6 +663,45 @@ def test_dropin_convergence_exits_follow_the_cpu_rule(gpu):
     # bad arguments: EXIT_FAILURE and the reference's message (src/lanczos_cuda.c:324-327)
     res, out, _ = run_dropin(a, 2, 1, 0.0)
     assert res["rc"] == 1 and "max_iter must be >= 2" in out
+
+
+def test_lanczos_takes_a_custom_matvec_plugin(gpu):
+    """lanczos() with a Matvec_General that is neither matvec_crs nor matvec_coo (src/lanczos.h:5,
+    call site src/lanczos.c:110): the plugin runs on host memory once per iteration, the vectors stay
+    on the GPU; Ritz values against the oracle run on the same operator, 1e-10 relative."""
+    import scipy.sparse as sp
+    a = la.synth_laplacian(2, 60)
+    n = a.dimension
+    m = sp.csr_matrix((a.values, a.column_index, a.row_head_indexes), shape=(n, n))
+    shift = np.linspace(0.0, 1.0, n)
+    calls = []
+
+    def apply(x):                     # A x + diag(shift) x, never materialised as a CRS matrix
+        calls.append(1)
+        return m @ x + shift * x
+
+    full = (m + sp.diags(shift)).tocsr()
+    full.sort_indices()
+    v0 = la.gaussian_fill(123456789, 0, n)     # the start vector lanczos() draws by default
+    o = oracle.lanczos_crs(full.indptr.astype(np.int64), full.indices.astype(np.int64), full.data, v0, 4, 81, 0.0)
+    eig = la.lanczos_plugin(apply, n, 4, 81, 0.0)
+    assert len(calls) == 80                    # one product per iteration (src/lanczos.c:104, 110)
+    assert rel_err(eig, o.eigenvalues) < 1e-10
+    # the handle API: the same operator set on an engine that holds an empty matrix
+    def cb(_mat, vec, dist):
+        np.ctypeslib.as_array(dist, (n,))[:] = apply(np.ctypeslib.as_array(vec, (n,)))
+    fn = la.MATVEC_FN(cb)
+    empty = la.CrsMatrix(np.zeros(0), np.zeros(0, np.int64), np.zeros(n + 1, np.int64))
+    for reorth in ("full", "selective", "none", "mgs"):
+        oo = oracle.lanczos_crs(full.indptr.astype(np.int64), full.indices.astype(np.int64), full.data, v0, 4, 41,
+                                0.0, reorth if reorth != "mgs" else "full")
+        with la.Engine(empty, 41, reorth=reorth) as e:
+            e.set_operator(fn)
+            assert e.spmv_name == "host_operator"
+            e.set_start(v0)
+            alpha, beta = e.run(40)
+        assert rel_err(la.ritz_values(alpha, beta, 40, 4), oo.eigenvalues) < 1e-10, reorth
+        assert rel_err(alpha[:20], oo.alpha[:20]) < 1e-11 and rel_err(beta[:20], oo.beta[:20]) < 1e-11, reorth
 
 
 def test_driver_binary_on_triplet_file(gpu, tmp_path):
