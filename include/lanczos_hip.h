@@ -82,6 +82,8 @@ typedef struct crs {
  *   LANCZOS_HIP_SEED    start-vector seed (default 123456789, the constant of
  *                       src/lanczos_cuda.c:395)
  *   LANCZOS_HIP_DEVICE  HIP device ordinal (default: current device)
+ *   LANCZOS_HIP_NGPU    number of GPUs: above 1 the matrix is row-partitioned over devices 0..N-1 of
+ *                       this node (lanczos_hip_multi_create below; no checkpoints or eigenvectors there)
  *   LANCZOS_HIP_QUIET   1 suppresses the per-iteration stdout lines
  *   LANCZOS_HIP_WINDOW  iterations enqueued ahead of the one the host is looking at (default 4)
  *   LANCZOS_HIP_PROFILE 0 drops the per-kernel events behind the [TOTAL] lines (default 1)
@@ -433,6 +435,40 @@ int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, d
 /* Copy alpha/beta history [0, iterations) from the device (row-partitioned
  * runs record the reduced values as the phases consume them). */
 int lanczos_hip_history(lanczos_hip_engine *e, double *alpha_out, double *beta_out, int count);
+
+/* ---- several GPUs of one node from one host process ------------------------
+ * No counterpart in the reference (one device, one stream: src/lanczos_cuda.c:364).  The matrix is cut
+ * into ngpu contiguous row slabs, one engine per slab on devices[p] (NULL: devices 0..ngpu-1); per
+ * iteration the slabs exchange the current vector (grouped ncclSend/ncclRecv into the tails of the
+ * neighbours' vectors when every remote column lives in an adjacent slab, beside the interior rows'
+ * product; ncclAllGather otherwise) and all-reduce alpha, then the reorthogonalisation coefficients
+ * together with w.w (one reduction of two doubles with LANCZOS_HIP_REORTH_NONE), all through RCCL on
+ * the engines' streams.  librccl.so.1 is opened when the first such handle is created.  options:
+ * reorth (any but LANCZOS_HIP_REORTH_MGS), spmv_kernel, profile; the rest is set per slab.
+ * LANCZOS_HIP_MULTI_LOOPBACK places every slab on ONE device (devices[0], else options.device, else
+ * 0) and replaces the collectives by copies and a summing kernel on one stream: the same partition,
+ * column remap and iteration order where only one GPU exists.
+ * lanczos_hip_crs() takes this path when LANCZOS_HIP_NGPU > 1 (LANCZOS_HIP_MULTI_LOOPBACK=1 for the
+ * loopback transport).  alpha/beta agree with the single-GPU run to rounding (sums are taken in
+ * another order), not bit for bit. */
+typedef struct lanczos_hip_multi lanczos_hip_multi;
+enum { LANCZOS_HIP_MULTI_LOOPBACK = 1 };
+int lanczos_hip_multi_create(lanczos_hip_multi **out, int ngpu, const int *devices, int64_t n, int64_t nnz,
+                             const int64_t *row_head_indexes, const int64_t *column_index, const double *values,
+                             int max_iter, const lanczos_hip_options *opt, int flags);
+void lanczos_hip_multi_destroy(lanczos_hip_multi *m);
+/* v0_host: the whole start vector (n doubles), normalised over all slabs; _seed draws it as
+ * lanczos_hip_set_start_seed does, so the run equals the single-GPU run of the same seed */
+int lanczos_hip_multi_set_start(lanczos_hip_multi *m, const double *v0_host);
+int lanczos_hip_multi_set_start_seed(lanczos_hip_multi *m, uint64_t seed);
+/* `steps` more iterations, then alpha/beta of those iterations (as lanczos_hip_run) */
+int lanczos_hip_multi_run(lanczos_hip_multi *m, int steps, double *alpha_out, double *beta_out);
+/* enqueue one iteration and return without waiting (what lanczos_hip_crs's host loop calls) */
+int lanczos_hip_multi_step(lanczos_hip_multi *m);
+/* the engine that holds slab `slab` (history, profile, kernel name; owned by the handle) */
+lanczos_hip_engine *lanczos_hip_multi_engine(lanczos_hip_multi *m, int slab);
+int lanczos_hip_multi_info(const lanczos_hip_multi *m, int *slabs, int *halo_exchange, int *overlapped, int *iterations,
+                           int *reorth_steps);
 
 /* ---- thick restart -------------------------------------------------------
  * No counterpart in the reference, which keeps every vector of a run and stops at max_iter

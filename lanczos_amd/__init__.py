@@ -752,6 +752,86 @@ class Engine:
         return alpha, beta
 
 
+_hip.lanczos_hip_multi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int64, C.c_int64,
+                                          _ip, _ip, _dp, C.c_int, C.POINTER(Options), C.c_int]
+_hip.lanczos_hip_multi_create.restype = C.c_int
+_hip.lanczos_hip_multi_destroy.argtypes = [C.c_void_p]
+_hip.lanczos_hip_multi_destroy.restype = None
+_hip.lanczos_hip_multi_set_start.argtypes = [C.c_void_p, _dp]
+_hip.lanczos_hip_multi_set_start_seed.argtypes = [C.c_void_p, C.c_uint64]
+_hip.lanczos_hip_multi_run.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+_hip.lanczos_hip_multi_step.argtypes = [C.c_void_p]
+_hip.lanczos_hip_multi_engine.argtypes = [C.c_void_p, C.c_int]
+_hip.lanczos_hip_multi_engine.restype = C.c_void_p
+_hip.lanczos_hip_multi_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+MULTI_LOOPBACK = 1
+
+
+class MultiEngine:
+    """Row slabs of one matrix on several GPUs, driven from this one process (RCCL), or all on one
+    GPU with loopback=True (copies and a summing kernel in place of the collectives)."""
+
+    def __init__(self, a: CrsMatrix, max_iter: int, ngpu: int, reorth: str = "full", spmv: str = "auto",
+                 loopback: bool = False, devices=None, profile: bool = False):
+        self._h = C.c_void_p(None)
+        self.n, self.max_iter, self.ngpu = a.dimension, max_iter, ngpu
+        opt = Options(C.sizeof(Options), -1, None, REORTH[reorth], SPMV[spmv], int(profile), 0, 0, 0, None, None, 0)
+        devs = (C.c_int * ngpu)(*devices) if devices is not None else None
+        _check(_hip.lanczos_hip_multi_create(C.byref(self._h), ngpu, devs, a.dimension, a.length,
+                                             a.row_head_indexes.ctypes.data_as(_ip),
+                                             a.column_index.ctypes.data_as(_ip), a.values.ctypes.data_as(_dp),
+                                             max_iter, C.byref(opt), MULTI_LOOPBACK if loopback else 0),
+               "lanczos_hip_multi_create")
+
+    def close(self):
+        if self._h:
+            _hip.lanczos_hip_multi_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_start(self, v0):
+        v0 = _f64(v0)
+        assert v0.shape[0] == self.n
+        _check(_hip.lanczos_hip_multi_set_start(self._h, v0.ctypes.data_as(_dp)), "lanczos_hip_multi_set_start")
+
+    def set_start_seed(self, seed: int):
+        _check(_hip.lanczos_hip_multi_set_start_seed(self._h, seed), "lanczos_hip_multi_set_start_seed")
+
+    def run(self, steps: int):
+        alpha, beta = np.zeros(steps), np.zeros(steps)
+        _check(_hip.lanczos_hip_multi_run(self._h, steps, alpha.ctypes.data_as(_dp), beta.ctypes.data_as(_dp)),
+               "lanczos_hip_multi_run")
+        return alpha, beta
+
+    def info(self) -> dict:
+        v = [C.c_int(0) for _ in range(5)]
+        _check(_hip.lanczos_hip_multi_info(self._h, *[C.byref(x) for x in v]), "lanczos_hip_multi_info")
+        return dict(zip(("slabs", "halo", "overlapped", "iterations", "reorth_steps"), (x.value for x in v)))
+
+    def slab_spmv_name(self, slab: int) -> str:
+        return _hip.lanczos_hip_spmv_name(_hip.lanczos_hip_multi_engine(self._h, slab)).decode()
+
+    def slab_profile(self, slab: int) -> dict:
+        h = _hip.lanczos_hip_multi_engine(self._h, slab)
+        out = {}
+        for i, name in enumerate(KERNEL_CLASSES):
+            ms, cnt, by = C.c_double(0), C.c_int64(0), C.c_double(0)
+            _check(_hip.lanczos_hip_profile(h, i, C.byref(ms), C.byref(cnt), C.byref(by)), "lanczos_hip_profile")
+            out[name] = {"ms": ms.value, "launches": cnt.value, "bytes": by.value}
+        return out
+
+
 def gather_base(n: int) -> int:
     """First x index of the remote entries of an engine that owns no basis (options.basis)."""
     return int(_hip.lanczos_hip_gather_base(n))

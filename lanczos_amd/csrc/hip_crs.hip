@@ -86,6 +86,9 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
         if (*s) seed = strtoull(s, NULL, 10);
 
     lz::Engine *e = nullptr;
+    lanczos_hip_multi *mg = nullptr;  // several GPUs: e is then the engine of slab 0, owned by mg
+    const int ngpu = env_int("LANCZOS_HIP_NGPU", 1);
+    const bool loopback = env_int("LANCZOS_HIP_MULTI_LOOPBACK", 0) != 0;
     std::vector<hipEvent_t> done((size_t)window, nullptr);
     std::vector<double> a((size_t)max_iter, 0.0), b((size_t)max_iter, 0.0), last((size_t)nth_eig, 0.0);
     const int total = max_iter - 1;
@@ -99,7 +102,17 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
     const char *resume_path = getenv("LANCZOS_HIP_RESUME");
 
-    if (mat) {
+    if (mat && (ngpu > 1 || loopback)) {
+        if ((resume_path && *resume_path) || (ckpt_path && *ckpt_path && ckpt_every > 0) || want_vectors) {
+            lz::fail("LANCZOS_HIP_NGPU: checkpoints and eigenvectors need the whole basis on one GPU");
+            goto cleanup;
+        }
+        if (lanczos_hip_multi_create(&mg, std::max(ngpu, 1), nullptr, (int64_t)dimension, (int64_t)length,
+                                     mat->row_head_indexes, mat->column_index, mat->values, max_iter, &opt,
+                                     loopback ? LANCZOS_HIP_MULTI_LOOPBACK : 0) != 0)
+            goto cleanup;
+        e = reinterpret_cast<lz::Engine *>(lanczos_hip_multi_engine(mg, 0));
+    } else if (mat) {
         if (lz::Engine::create(&e, (int64_t)dimension, (int64_t)length, mat->row_head_indexes, mat->column_index,
                                mat->values, max_iter, &opt) != 0)
             goto cleanup;
@@ -110,7 +123,13 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
         if (e->set_operator(op, op_mat) != 0) goto cleanup;
     }
     if (e->enable_host_history() != 0) goto cleanup;
-    {
+    if (mg) {
+        int halo = 0, over = 0;
+        if (lanczos_hip_multi_set_start_seed(mg, seed) != 0) goto cleanup;
+        lanczos_hip_multi_info(mg, NULL, &halo, &over, NULL, NULL);
+        fprintf(stderr, "[INIT] name=row_slabs count=%d transport=%s exchange=%s overlapped=%d\n", std::max(ngpu, 1),
+                loopback ? "loopback" : "rccl", halo ? "halo" : "allgather", over);
+    } else {
         std::vector<double> v0(dimension);
         lanczos_hip_gaussian_fill(seed, 0, (int64_t)dimension, v0.data());
         if (e->set_start(v0.data(), true, 1.0) != 0) goto cleanup;
@@ -136,7 +155,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
 
     for (int k = 0; k < total; k++) {
         while (enq < total && enq < k + window) {
-            if (e->enqueue_iteration() != 0) goto cleanup;
+            if ((mg ? lanczos_hip_multi_step(mg) : e->enqueue_iteration()) != 0) goto cleanup;
             if (hipEventRecord(done[(size_t)(enq % window)], e->stream) != hipSuccess) {
                 lz::fail("hipEventRecord failed");
                 goto cleanup;
@@ -230,6 +249,7 @@ cleanup:
     if (e) {
         iterations = e->k;
         reorth_steps = e->reorth_steps;
+        if (mg) lanczos_hip_multi_info(mg, NULL, NULL, NULL, &iterations, &reorth_steps);
         snprintf(kernel_name, sizeof kernel_name, "%s", e->spmv_name);
         (void)hipStreamSynchronize(e->stream);
         e->harvest_profile();
@@ -238,7 +258,10 @@ cleanup:
     }
     for (auto ev : done)
         if (ev) (void)hipEventDestroy(ev);
-    delete e;
+    if (mg)
+        lanczos_hip_multi_destroy(mg);
+    else
+        delete e;
     // the grammar of src/lanczos_cuda.c:782-786 (no T upload exists here, so no cudaMemcpy line)
     fprintf(stderr, "[TOTAL] name=init detail_ref=INIT sec=%.6f\n", time_init);
     fprintf(stderr, "[TOTAL] name=spmv sec=%.6f\n", t_spmv);

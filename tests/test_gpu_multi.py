@@ -1,0 +1,161 @@
+"""Several row slabs driven from one host process (lanczos_hip_multi_*, LANCZOS_HIP_NGPU).
+
+The reference has no multi-GPU code; the slabs must reproduce the single-GPU run, which the other
+tests tie to the oracle.  A one-GPU box holds every slab on cuda:0 (loopback transport: copies and
+a summing kernel where a node runs RCCL), which exercises the partition, the column remap, both
+exchange forms, the split product and the iteration order; RCCL itself runs with one slab.
+Tolerances: alpha/beta 1e-11 relative to the single engine (sums are taken in another order),
+Ritz values 1e-10 relative to the oracle."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import lanczos_amd as la
+import oracle
+from matrices import rel_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def single(a, v0, steps, reorth):
+    with la.Engine(a, steps + 1, reorth=reorth) as e:
+        e.set_start(v0)
+        return e.run(steps)
+
+
+@pytest.mark.parametrize("reorth", ["full", "full2", "cuda_compat", "none", "selective"])
+def test_loopback_slabs_match_the_single_engine_and_the_oracle(gpu, reorth):
+    steps = 60
+    for a, slabs, want_halo in ((la.synth_laplacian(3, 24), 3, True), (la.synth_laplacian(2, 90), 2, True),
+                                (la.synth_random_symmetric(20000, 6, 5), 3, False)):
+        v0 = la.gaussian_fill(7, 0, a.dimension)
+        a1, b1 = single(a, v0, steps, reorth)
+        with la.MultiEngine(a, steps + 1, slabs, reorth=reorth, loopback=True) as m:
+            info = m.info()
+            assert info["slabs"] == slabs and bool(info["halo"]) == want_halo
+            if want_halo:
+                assert info["overlapped"] == 1       # stencil slabs: the split product is exercised
+            m.set_start(v0)
+            a2, b2 = m.run(steps)
+            assert m.info()["iterations"] == steps
+        # without reorthogonalisation rounding differences grow with the loss of orthogonality: the
+        # sequences are compared while they are still determined (25 steps), the others throughout
+        cmp = 25 if reorth == "none" else steps
+        assert rel_err(a2[:cmp], a1[:cmp]) < 1e-11 and rel_err(b2[:cmp], b1[:cmp]) < 1e-11, (reorth, slabs)
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, cmp + 1, 0.0,
+                               reorth if reorth in ("full", "none", "selective", "cuda_compat") else "full")
+        assert rel_err(la.ritz_values(a2, b2, cmp, 4), o.eigenvalues) < 1e-10, (reorth, slabs)
+
+
+def test_loopback_forced_allgather_and_unsplit_product(gpu, monkeypatch):
+    a = la.synth_laplacian(3, 20)
+    v0 = la.gaussian_fill(3, 0, a.dimension)
+    a1, b1 = single(a, v0, 40, "full")
+    monkeypatch.setenv("LANCZOS_HIP_MULTI_ALLGATHER", "1")
+    with la.MultiEngine(a, 41, 4, loopback=True) as m:
+        assert m.info()["halo"] == 0
+        m.set_start(v0)
+        a2, b2 = m.run(40)
+    assert rel_err(a2, a1) < 1e-11 and rel_err(b2, b1) < 1e-11
+    monkeypatch.delenv("LANCZOS_HIP_MULTI_ALLGATHER")
+    monkeypatch.setenv("LANCZOS_HIP_MULTI_NO_OVERLAP", "1")
+    with la.MultiEngine(a, 41, 4, loopback=True) as m:
+        assert m.info()["halo"] == 1 and m.info()["overlapped"] == 0
+        m.set_start(v0)
+        a3, b3 = m.run(40)
+    assert rel_err(a3, a1) < 1e-11 and rel_err(b3, b1) < 1e-11
+    # runs continue over several calls; a second start vector resets the run
+    monkeypatch.delenv("LANCZOS_HIP_MULTI_NO_OVERLAP")
+    with la.MultiEngine(a, 41, 2, loopback=True, reorth="none") as m:
+        m.set_start(v0)
+        pa, pb = m.run(15)
+        qa, qb = m.run(25)
+        an, bn = single(a, v0, 40, "none")
+        assert rel_err(np.concatenate([pa, qa])[:25], an[:25]) < 1e-11
+        assert rel_err(np.concatenate([pb, qb])[:25], bn[:25]) < 1e-11
+        m.set_start(v0)
+        ra, rb = m.run(40)
+        assert np.array_equal(ra, np.concatenate([pa, qa]))
+
+
+def test_rccl_transport_with_one_slab(gpu):
+    """ncclCommInitAll over the one device of this box: every collective of an iteration goes through
+    RCCL with world size 1; the sequences are the single engine's to rounding (1e-12 relative)."""
+    a = la.synth_laplacian(3, 32)
+    v0 = la.gaussian_fill(11, 0, a.dimension)
+    for reorth in ("none", "full", "selective"):
+        a1, b1 = single(a, v0, 50, reorth)
+        with la.MultiEngine(a, 51, 1, reorth=reorth, loopback=False) as m:
+            m.set_start(v0)
+            a2, b2 = m.run(50)
+        cmp = 25 if reorth == "none" else 50
+        assert rel_err(a2[:cmp], a1[:cmp]) < 1e-12 and rel_err(b2[:cmp], b1[:cmp]) < 1e-12, reorth
+
+
+def test_more_gpus_than_visible_and_mgs_are_refused(gpu):
+    a = la.synth_laplacian(1, 5000)
+    import torch
+    with pytest.raises(la.LanczosHipError, match="more GPUs than this process sees"):
+        la.MultiEngine(a, 11, torch.cuda.device_count() + 1)
+    with pytest.raises(la.LanczosHipError, match="mgs"):
+        la.MultiEngine(a, 11, 2, reorth="mgs", loopback=True)
+    with pytest.raises(la.LanczosHipError, match="fewer rows"):
+        la.MultiEngine(la.synth_laplacian(1, 3), 3, 4, loopback=True)
+
+
+def _dropin(a, nth, max_iter, thr, env):
+    code = ("import sys, json, numpy as np, lanczos_amd as la\n"
+            "d=np.load(sys.argv[1])\n"
+            "a=la.CrsMatrix(d['v'],d['c'],d['h'])\n"
+            f"rc,eig=la.lanczos_hip_crs(a,{nth},{max_iter},{thr!r})\n"
+            "sys.stdout.flush()\n"
+            "print('RESULT '+json.dumps({'rc':rc,'eig':[float(x) for x in eig]}))\n")
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "m.npz")
+        np.savez(path, v=a.values, c=a.column_index, h=a.row_head_indexes)
+        r = subprocess.run([sys.executable, "-c", code, path], cwd=ROOT, capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
+    return res, r.stdout, r.stderr
+
+
+def test_dropin_honours_ngpu(gpu):
+    """lanczos_hip_crs with LANCZOS_HIP_NGPU: same lines, same exits, same values as on one GPU."""
+    a = la.synth_laplacian(2, 100)
+    v0 = la.gaussian_fill(123456789, 0, a.dimension)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 101, 0.0)
+    for reorth in ("full", "selective"):
+        oo = o if reorth == "full" else oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 101,
+                                                           0.0, reorth)
+        res, out, err = _dropin(a, 4, 101, 0.0, {"LANCZOS_HIP_NGPU": "3", "LANCZOS_HIP_MULTI_LOOPBACK": "1",
+                                                 "LANCZOS_HIP_REORTH": reorth, "LANCZOS_HIP_JSON": "1"})
+        assert res["rc"] == 0 and rel_err(res["eig"], oo.eigenvalues) < 1e-10, reorth
+        assert "[INIT] name=row_slabs count=3 transport=loopback exchange=halo" in err
+        step_lines = [ln for ln in out.splitlines() if ln[:1].isdigit() and "\t" in ln]
+        assert len(step_lines) == 100 and "Reached max iterations (101)" in out
+        assert step_lines[49] == "50\t" + "\t".join(f"{x:.7f}" for x in oo.ritz_hist[49]) + "\t"
+        rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
+        assert rec["iterations"] == 100 and rec["exit_kind"] == 0
+    # the convergence exit through the slabs, and RCCL with one slab behind the same entry
+    thr = 1e-2
+    b = la.synth_laplacian(1, 2000)
+    ob = oracle.lanczos_crs(b.row_head_indexes, b.column_index, b.values, la.gaussian_fill(123456789, 0, 2000), 2, 400, thr)
+    res, out, err = _dropin(b, 2, 400, thr, {"LANCZOS_HIP_NGPU": "2", "LANCZOS_HIP_MULTI_LOOPBACK": "1",
+                                             "LANCZOS_HIP_JSON": "1"})
+    rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
+    assert res["rc"] == 0 and rec["exit_kind"] == ob.exit_kind == 1 and rec["exit_step"] == ob.steps
+    # asking for more GPUs than there are fails cleanly with EXIT_FAILURE and a message
+    import torch
+    res, out, _ = _dropin(a, 4, 21, 0.0, {"LANCZOS_HIP_NGPU": str(torch.cuda.device_count() + 1)})
+    assert res["rc"] == 1 and "more GPUs than this process sees" in out
+    # checkpoints are refused there
+    res, out, _ = _dropin(a, 4, 21, 0.0, {"LANCZOS_HIP_NGPU": "2", "LANCZOS_HIP_MULTI_LOOPBACK": "1",
+                                          "LANCZOS_HIP_CHECKPOINT": "/tmp/x.ckpt", "LANCZOS_HIP_CHECKPOINT_EVERY": "5"})
+    assert res["rc"] == 1 and "whole basis on one GPU" in out
