@@ -3,12 +3,14 @@
 small text summaries kept under profiles/.
 
 usage: summarize_profile.py <tag> <kernel_stats.csv> [<fetch_counter_collection.csv> <write_counter_collection.csv>
-                            [<traffic.json> <workload> <steps> <reorth>]]
+                            [<traffic.json> <workload> <steps> <reorth> <bench_line.json>]]
 
-With the last four arguments it also writes the per-launch HBM bytes of every kernel class
-(2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) that bench.py reports as roofline.traffic.  For the
-reorthogonalisation kernels only the last steps-1 launches count (those of the timed run; the
-warm-up iterations launched them before with a nearly empty basis).
+With the last five arguments (the command profiled is `bench.py --main-only --steps <steps>`, whose JSON
+line is the last argument) it also writes, for every kernel class,
+the ratio of measured HBM bytes (2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes) to the algorithmic bytes
+of the same launches: what bench.py multiplies its own launches' algorithmic bytes with to report
+roofline.traffic at any --steps.  Only the launches of the timed run count (the last `steps` of a class,
+steps-1 for the reorthogonalisation kernels; the warm-up launched them before).
 """
 import collections
 import csv
@@ -47,20 +49,29 @@ def main():
             f = sum(v["f"]) / len(v["f"])
             w = sum(v["w"]) / max(len(v["w"]), 1)
             out.append(f"| {k} | {len(v['f'])} | {f:.0f} | {2*f*1024/1e6:.1f} | {w:.0f} | {w*1024/1e6:.1f} |")
-        if len(sys.argv) >= 9:
+        if len(sys.argv) >= 10:
             path, workload, steps, reorth = sys.argv[5], sys.argv[6], int(sys.argv[7]), sys.argv[8]
-            per = {}
+            # the JSON line bench.py printed in the kernel-trace pass
+            bench = json.loads(open(sys.argv[9]).read().strip().splitlines()[-1])
+            alg, launches = bench["kernel_algorithmic_bytes_total"], bench["kernel_launches"]
+            measured, ratio = {}, {}
             for k, v in agg.items():
                 cls = next((c for key, c in CLASS_OF if key in k), None)
                 if cls is None or not v["f"] or not v["w"]:
                     continue
-                f, w = v["f"], v["w"]
-                if cls in ("dots", "update"):
-                    f, w = f[-(steps - 1):], w[-(steps - 1):]
-                per[cls] = 2 * 1024 * sum(f) / len(f) + 1024 * sum(w) / len(w)
+                cnt = int(launches.get(cls, 0))
+                if cnt <= 0 or len(v["f"]) < cnt or len(v["w"]) < cnt:
+                    continue
+                f, w = v["f"][-cnt:], v["w"][-cnt:]
+                measured[cls] = measured.get(cls, 0.0) + 2 * 1024 * sum(f) + 1024 * sum(w)
+            for cls, b in measured.items():
+                if alg.get(cls, 0) > 0:
+                    ratio[cls] = b / alg[cls]
             json.dump({"workload": workload, "steps": steps, "reorth": reorth, "source": tag,
-                       "rule": "2 x FETCH_SIZE + WRITE_SIZE (KiB), averaged per launch; separate --pmc passes",
-                       "bytes_per_launch": per}, open(path, "w"), indent=1)
+                       "rule": "(2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, summed over the timed run's launches of a "
+                               "class) / (algorithmic bytes of the same launches); separate --pmc passes",
+                       "spmv_kernel": bench["config"]["spmv_kernel"],
+                       "measured_over_algorithmic": ratio}, open(path, "w"), indent=1)
     print("\n".join(out))
 
 
