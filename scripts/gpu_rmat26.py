@@ -29,62 +29,16 @@ def log(msg):
 
 
 T0 = time.perf_counter()
+sys.path.insert(0, "tests")
+from matrices import rmat_laplacian_gpu  # noqa: E402
+
 n = 1 << scale
-m = edge_factor * n
-g = torch.Generator(device=dev)
-g.manual_seed(seed)
-rows = torch.zeros(m, dtype=torch.int64, device=dev)
-cols = torch.zeros(m, dtype=torch.int64, device=dev)
-for level in range(scale):
-    r = torch.rand(m, generator=g, device=dev, dtype=torch.float32)
-    down = r >= pa + pb                                    # quadrants c and d
-    right = ((r >= pa) & (r < pa + pb)) | (r >= pa + pb + pc)  # quadrants b and d
-    rows |= down.to(torch.int64) << level
-    cols |= right.to(torch.int64) << level
-    del r, down, right
-keep = rows != cols
-rows, cols = rows[keep], cols[keep]
-del keep
-fwd = (rows << 32) | cols
-rev = (cols << 32) | rows
-del rows, cols
-torch.cuda.synchronize()
-log(f"edges drawn: {fwd.numel()} without self-loops")
-
-# sort + merge per row range; every range holds fewer than 2^31 keys (ranges sized from the row histogram)
-parts = 16
-cut = [(n * p // parts) << 32 for p in range(parts + 1)]
-pieces = []
-for p in range(parts):
-    lo, hi = cut[p], cut[p + 1]
-    diag = torch.arange(n * p // parts, n * (p + 1) // parts, dtype=torch.int64, device=dev)
-    k = torch.cat([fwd[(fwd >= lo) & (fwd < hi)], rev[(rev >= lo) & (rev < hi)], (diag << 32) | diag])
-    assert k.numel() < 2 ** 31 - 1, "row range too large for one sort"
-    pieces.append(torch.unique(k))
-    del k, diag
-del fwd, rev
-keys = torch.cat(pieces)
-del pieces
-nnz = keys.numel()
-torch.cuda.synchronize()
-log(f"merged: n={n} nnz={nnz} (2^31={2 ** 31})")
-
-bounds = torch.arange(n + 1, dtype=torch.int64, device=dev) << 32
-row_head = torch.searchsorted(keys, bounds)
-del bounds
-lens = row_head[1:] - row_head[:-1]
-max_row = int(lens.max())
-rows_over_512 = int((lens > 512).sum())
-isolated = int((lens <= 1).sum())
-col = keys & 0xFFFFFFFF
-row = keys >> 32
-del keys
-val = torch.where(col == row, (lens - 1).to(torch.float64)[row], torch.tensor(-1.0, dtype=torch.float64, device=dev))
-del row, lens
-h_col, h_val, h_head = col.cpu().numpy(), val.cpu().numpy(), row_head.cpu().numpy()
-del col, val, row_head
-torch.cuda.empty_cache()
-log(f"on the host: max row {max_row}, rows over 512 entries {rows_over_512}, isolated vertices {isolated}")
+h_val, h_col, h_head = rmat_laplacian_gpu(scale, edge_factor, seed, (pa, pb, pc))
+nnz = h_val.shape[0]
+lens_h = np.diff(h_head)
+max_row, rows_over_512, isolated = int(lens_h.max()), int((lens_h > 512).sum()), int((lens_h <= 1).sum())
+del lens_h
+log(f"on the host: n={n} nnz={nnz}, max row {max_row}, rows over 512 entries {rows_over_512}, isolated vertices {isolated}")
 
 a = la.CrsMatrix(h_val, h_col, h_head)
 out = {"scale": scale, "n": n, "nnz": nnz, "max_row": max_row, "rows_over_512": rows_over_512,

@@ -90,3 +90,81 @@ def test_bench_line_keeps_its_contract(gpu):
     assert d["selective_reorth"]["ritz_rel_diff_vs_full"] < 1e-10
     assert d["strong_scaling_laplacian"]["iters_per_s"] > 0
     assert d["converged_run"]["steps"] == 40 and d["converged_run"]["seconds"] > 0
+
+
+def _sampled_rows_agree(a, u, au, rows):
+    h, c, v = a.row_head_indexes, a.column_index, a.values
+    for r in rows:
+        sl = slice(h[r], h[r + 1])
+        want = float(np.dot(v[sl], u[c[sl]]))
+        scale_r = float(np.abs(v[sl]) @ np.abs(u[c[sl]]))
+        assert abs(au[r] - want) <= 1e-13 * (1 + scale_r), (r, au[r], want)
+
+
+def test_random_symmetric_50m_rows(gpu):
+    """The irregular-rows configuration at its full size (n = 50 000 000, about 21 entries per row,
+    nnz ~ 1.05e9): the row sums in closed form, symmetry, sampled rows against direct evaluation, and
+    the first steps against the CPU restatement."""
+    import time
+    t0 = time.perf_counter()
+    a = la.synth_random_symmetric(50_000_000, 10, 42)
+    n = a.dimension
+    print(f"[{time.perf_counter() - t0:.0f}s] generated n={n} nnz={a.length}", flush=True)
+    rng = np.random.default_rng(3)
+    with la.Engine(a, 8, reorth="none") as e:
+        print(f"[{time.perf_counter() - t0:.0f}s] engine up, kernel {e.spmv_name}", flush=True)
+        assert e.spmv_name.startswith("panel")
+        # A * ones = row sums, evaluated on the host in one pass
+        want = np.add.reduceat(a.values, a.row_head_indexes[:-1])
+        got = e.spmv(np.ones(n))
+        assert np.max(np.abs(got - want)) <= 1e-13 * 64
+        u, v = rng.standard_normal(n), rng.standard_normal(n)
+        au, av = e.spmv(u), e.spmv(v)
+        lhs, rhs = float(v @ au), float(u @ av)
+        assert abs(lhs - rhs) <= 1e-11 * (np.linalg.norm(u) * np.linalg.norm(av)), (lhs, rhs)
+        _sampled_rows_agree(a, u, au, np.concatenate([rng.integers(0, n, 3000), [0, 1, n - 1]]))
+        print(f"[{time.perf_counter() - t0:.0f}s] SpMV checks passed", flush=True)
+        v0 = la.gaussian_fill(123456789, 0, n)
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 2, 5, 0.0, "none")
+        e.set_start(v0)
+        alpha, beta = e.run(4)
+        assert np.max(np.abs(alpha - o.alpha) / np.abs(o.alpha)) < 1e-12
+        assert np.max(np.abs(beta - o.beta) / np.abs(o.beta)) < 1e-12
+    print(f"[{time.perf_counter() - t0:.0f}s] done", flush=True)
+
+
+def test_rmat_scale_26_graph_laplacian(gpu):
+    """The power-law configuration at its full size (R-MAT scale 26, edge factor 16: n = 67 108 864, more
+    than 2^31 entries, longest row about a million entries, half of the vertices isolated): L * ones = 0
+    exactly, symmetry, sampled rows (the five longest among them), finite positive recurrence scalars,
+    and one block step of the fp64 matrix-core variant with an orthonormal result."""
+    import time
+    from matrices import rmat_laplacian_gpu
+    t0 = time.perf_counter()
+    a = la.CrsMatrix(*rmat_laplacian_gpu(26))
+    n = a.dimension
+    print(f"[{time.perf_counter() - t0:.0f}s] generated n={n} nnz={a.length}", flush=True)
+    assert a.length > 2 ** 31
+    rng = np.random.default_rng(1)
+    with la.Engine(a, 9, reorth="none") as e:
+        print(f"[{time.perf_counter() - t0:.0f}s] engine up, kernel {e.spmv_name}", flush=True)
+        assert e.spmv_name.endswith("_rp64")
+        assert not e.spmv(np.ones(n)).any(), "L * ones must vanish exactly"
+        u, v = rng.standard_normal(n), rng.standard_normal(n)
+        au, av = e.spmv(u), e.spmv(v)
+        lhs, rhs = float(v @ au), float(u @ av)
+        assert abs(lhs - rhs) <= 1e-11 * (np.linalg.norm(u) * np.linalg.norm(av)), (lhs, rhs)
+        heavy = np.argsort(np.diff(a.row_head_indexes))[-5:]
+        _sampled_rows_agree(a, u, au, np.concatenate([rng.integers(0, n, 2000), [0, 1, n - 1], heavy]))
+        print(f"[{time.perf_counter() - t0:.0f}s] SpMV checks passed", flush=True)
+        e.set_start_seed(1)
+        alpha, beta = e.run(8)
+        assert np.all(np.isfinite(alpha)) and np.all(beta > 0)
+    del au, av, u, v
+    with la.BlockEngine(a, 2) as b:
+        b.set_start_seed(1)
+        b.run(1)
+        q0, q1 = b.get_block(0), b.get_block(1)
+        assert np.max(np.abs(q1.T @ q1 - np.eye(16))) < 1e-12 and np.max(np.abs(q0.T @ q1)) < 1e-12
+        assert np.all(np.isfinite(b.ritz(4, 1)))
+    print(f"[{time.perf_counter() - t0:.0f}s] done", flush=True)
