@@ -1,8 +1,9 @@
 """A few Lanczos steps (no reorthogonalisation) on the random symmetric matrix: for rocprofv3 passes."""
 import sys
 
-sys.path.insert(0, ".")
-sys.path.insert(0, "/root/repo")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import lanczos_amd as la
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000

@@ -1,7 +1,9 @@
 """SpMV time of chosen forms on the 3-D Laplacian N^3 (run on the GPU box): gpu_spmv_forms.py N form [form ...]"""
 import sys
 
-sys.path.insert(0, ".")
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import lanczos_amd as la
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
