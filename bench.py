@@ -495,7 +495,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or args.force_dist:
         from lanczos_amd.dist import bench_distributed
-        out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS)
+        out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS, json_fd)
     else:
         out = single_gpu(args)
     sys.stdout.flush()

@@ -504,7 +504,7 @@ def _timed_dist_run(torch, dist, runner, v0, steps, warm):
     return float(t.item())
 
 
-def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
+def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None):
     """bench.py for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
     import torch.distributed as dist
@@ -587,83 +587,71 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
             "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
             "ritz_lowest4": [float(x) for x in ritz],
         }
-    # ---- the SpMV + vector step on its own (no reorthogonalisation), same slabs
+    # The primary figure stands from here on.  What follows are secondary sections; should one of them
+    # hang on some rank (they have never run on more than one GPU), every rank leaves after a deadline and
+    # rank 0 prints the line as it stands, so the run still reports its metric.
+    import json
+    import sys
+    import threading
+    state = {"done": False}
+
+    def _bail():
+        if state["done"]:
+            return
+        if rank == 0 and out is not None:
+            out["secondary_sections"] = "abandoned at the deadline"
+            os.write(json_fd if json_fd is not None else 1, (json.dumps(out) + "\n").encode())
+        os._exit(0)
+
+    deadline = float(os.environ.get("LANCZOS_BENCH_SECONDARY_DEADLINE_S", "900"))
+    timer = threading.Timer(deadline, _bail)
+    timer.daemon = True
+    timer.start()
+
+    def section(name, fn):
+        """A secondary section; an error is recorded in the line instead of ending the run.  Errors that
+        come from the configuration are the same on every rank, so the ranks stay in step."""
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            if rank == 0:
+                out.setdefault("section_errors", {})[name] = f"{type(exc).__name__}: {exc}"[:300]
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
     steps2 = 100
     del runner
     torch.cuda.empty_cache()
-    r2 = build_gpu_rank(la, torch, comm, a_local, bounds, 4, reorth="none", spmv=args.spmv, profile=True)
-    dt2 = _timed_dist_run(torch, dist, r2, v0, steps2, 5)
-    r2.history()                       # drains the stream and collects the kernel timings
-    p2 = r2.engine.e.profile()
-    if rank == 0:
-        b = algorithmic_bytes(n, nnz)
-        # bytes of the matrix format in use on rank 0's slab (CRS or row-pattern dictionary), times the ranks
-        fmt_iter = (p2["spmv"]["bytes"] / steps2 + 64.0 * (bounds[1] - bounds[0])) * world
-        out["spmv_vector_step"] = {
-            "iters_per_s": steps2 / dt2,
-            "ms_per_iter": dt2 / steps2 * 1e3,
-            "spmv_kernel": r2.engine.e.spmv_name,
-            "format_bytes_per_iter": fmt_iter,
-            "frac_of_hbm_peak": fmt_iter * steps2 / dt2 / 1e9 / (hbm_peak * world),
-            "crs_algorithmic_bytes_per_iter": b["iter"],
-            "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt2 / 1e9,
-            "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
-            "exchange": r2.plan.mode,
-            "all_reduces_per_step": 1 if r2.lazy else 2,
-            "exchange_overlapped_with_product": r2.interior is not None,
-        }
-    del r2
-    torch.cuda.empty_cache()
-    # ---- irregular rows: random symmetric matrix, nnz-balanced slabs, all-gather exchange
-    if getattr(args, "rand_rows", 0) > 0:
-        # every rank builds its own slab (the rows hold ~21 entries each with little spread, so equal
-        # row counts are equal entry counts to a fraction of a per cent)
-        nr = args.rand_rows
-        rb = partition_rows(nr, world)
-        mine = la.synth_random_symmetric_rows(nr, 10, 42, rb[rank], rb[rank + 1])
-        nz3 = torch.tensor([float(mine.length)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(nz3)
-        nnz_r = int(nz3.item())
-        r3 = build_gpu_rank(la, torch, comm, mine, rb, 4, reorth="none", spmv=args.spmv, profile=True)
-        v3 = la.gaussian_fill(123456789, rb[rank], rb[rank + 1] - rb[rank])
-        dt3 = _timed_dist_run(torch, dist, r3, v3, steps2, 5)
-        r3.history()
-        p3 = r3.engine.e.profile()
+
+    def sec_vector_step():
+        # the SpMV + vector step on its own (no reorthogonalisation), same slabs
+        r2 = build_gpu_rank(la, torch, comm, a_local, bounds, 4, reorth="none", spmv=args.spmv, profile=True)
+        dt2 = _timed_dist_run(torch, dist, r2, v0, steps2, 5)
+        r2.history()                       # drains the stream and collects the kernel timings
+        p2 = r2.engine.e.profile()
         if rank == 0:
-            b = algorithmic_bytes(nr, nnz_r)
-            out["random_symmetric"] = {
-                "workload": f"random symmetric n={nr}, nnz={nnz_r} ({nnz_r / nr:.1f} per row), seed 42, "
-                            f"equal row slabs over {world} GPUs",
-                "steps": steps2,
-                "iters_per_s": steps2 / dt3,
-                "ms_per_iter": dt3 / steps2 * 1e3,
-                "algorithmic_bytes_per_iter": b["iter"],
-                "frac_of_hbm_peak": b["iter"] * steps2 / dt3 / 1e9 / (hbm_peak * world),
-                "spmv_avg_ms_rank0": p3["spmv"]["ms"] / steps2,
-                "exchange": r3.plan.mode,
+            b = algorithmic_bytes(n, nnz)
+            # bytes of the matrix format in use on rank 0's slab (CRS or row-pattern dictionary), times the ranks
+            fmt_iter = (p2["spmv"]["bytes"] / steps2 + 64.0 * (bounds[1] - bounds[0])) * world
+            out["spmv_vector_step"] = {
+                "iters_per_s": steps2 / dt2,
+                "ms_per_iter": dt2 / steps2 * 1e3,
+                "spmv_kernel": r2.engine.e.spmv_name,
+                "format_bytes_per_iter": fmt_iter,
+                "frac_of_hbm_peak": fmt_iter * steps2 / dt2 / 1e9 / (hbm_peak * world),
+                "crs_algorithmic_bytes_per_iter": b["iter"],
+                "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt2 / 1e9,
+                "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
+                "exchange": r2.plan.mode,
+                "all_reduces_per_step": 1 if r2.lazy else 2,
+                "exchange_overlapped_with_product": r2.interior is not None,
             }
-        del r3
-    # ---- time to solution: selective reorthogonalisation until the lowest eigenvalue stands
-    conv = getattr(args, "converge_steps", 0)
-    if conv > 0 and d == 3:
-        torch.cuda.empty_cache()
-        r5 = build_gpu_rank(la, torch, comm, a_local, bounds, conv + 1, reorth="selective", spmv=args.spmv)
-        dt5 = _timed_dist_run(torch, dist, r5, v0, conv, 2)
-        a5, b5 = r5.history()
-        if rank == 0:
-            exact = 3.0 * (2.0 - 2.0 * np.cos(np.pi / (N + 1)))
-            lowest = float(la.ritz_values(a5, b5, conv, 1)[0])
-            out["converged_run"] = {
-                "reorth": "selective", "steps": conv, "seconds": dt5, "iters_per_s": conv / dt5,
-                "steps_that_reorthogonalised": r5.reorth_steps,
-                "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
-            }
-        del r5
-        torch.cuda.empty_cache()
-    # ---- strong scaling on the large grid (SpMV + vector step): the matrix whose 300-vector basis
-    # does not fit one GPU; every rank generates its own slab
-    big = getattr(args, "big_grid", 0)
-    if big > 0:
+
+    def sec_big_grid():
+        # strong scaling on the large grid (SpMV + vector step): the matrix whose 300-vector basis
+        # does not fit one GPU; every rank generates its own slab
+        big = args.big_grid
         nb = big ** 3
         bb = partition_rows(nb, world)
         slab = la.synth_laplacian_rows(3, big, bb[rank], bb[rank + 1])
@@ -691,7 +679,60 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak):
                 "exchange": r4.plan.mode,
                 "exchange_overlapped_with_product": r4.interior is not None,
             }
-        del r4
+
+    def sec_random():
+        # irregular rows: random symmetric matrix, all-gather exchange.  Every rank builds its own slab (the
+        # rows hold ~21 entries each with little spread, so equal row counts are equal entry counts to a
+        # fraction of a per cent)
+        nr = args.rand_rows
+        rb = partition_rows(nr, world)
+        mine = la.synth_random_symmetric_rows(nr, 10, 42, rb[rank], rb[rank + 1])
+        nz3 = torch.tensor([float(mine.length)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(nz3)
+        nnz_r = int(nz3.item())
+        r3 = build_gpu_rank(la, torch, comm, mine, rb, 4, reorth="none", spmv=args.spmv, profile=True)
+        v3 = la.gaussian_fill(123456789, rb[rank], rb[rank + 1] - rb[rank])
+        dt3 = _timed_dist_run(torch, dist, r3, v3, steps2, 5)
+        r3.history()
+        p3 = r3.engine.e.profile()
+        if rank == 0:
+            b = algorithmic_bytes(nr, nnz_r)
+            out["random_symmetric"] = {
+                "workload": f"random symmetric n={nr}, nnz={nnz_r} ({nnz_r / nr:.1f} per row), seed 42, "
+                            f"equal row slabs over {world} GPUs",
+                "steps": steps2,
+                "iters_per_s": steps2 / dt3,
+                "ms_per_iter": dt3 / steps2 * 1e3,
+                "algorithmic_bytes_per_iter": b["iter"],
+                "frac_of_hbm_peak": b["iter"] * steps2 / dt3 / 1e9 / (hbm_peak * world),
+                "spmv_avg_ms_rank0": p3["spmv"]["ms"] / steps2,
+                "exchange": r3.plan.mode,
+            }
+
+    def sec_converge():
+        # time to solution: selective reorthogonalisation until the lowest eigenvalue stands
+        conv = args.converge_steps
+        r5 = build_gpu_rank(la, torch, comm, a_local, bounds, conv + 1, reorth="selective", spmv=args.spmv)
+        dt5 = _timed_dist_run(torch, dist, r5, v0, conv, 2)
+        a5, b5 = r5.history()
+        if rank == 0:
+            exact = 3.0 * (2.0 - 2.0 * np.cos(np.pi / (N + 1)))
+            lowest = float(la.ritz_values(a5, b5, conv, 1)[0])
+            out["converged_run"] = {
+                "reorth": "selective", "steps": conv, "seconds": dt5, "iters_per_s": conv / dt5,
+                "steps_that_reorthogonalised": r5.reorth_steps,
+                "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
+            }
+
+    section("spmv_vector_step", sec_vector_step)
+    if getattr(args, "big_grid", 0) > 0:
+        section("strong_scaling_laplacian", sec_big_grid)
+    if getattr(args, "rand_rows", 0) > 0:
+        section("random_symmetric", sec_random)
+    if getattr(args, "converge_steps", 0) > 0 and d == 3:
+        section("converged_run", sec_converge)
+    state["done"] = True
+    timer.cancel()
     dist.barrier()
     dist.destroy_process_group()
     return out
