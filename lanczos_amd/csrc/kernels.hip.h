@@ -604,23 +604,25 @@ k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__
         lo = rp[r];
         hi = rp[r < n ? r + 1 : n];
     };
-    // The tile of a group starts at its span rounded down to a multiple of four entries, so that
-    // every lane loads 16 bytes at a time: two loads of four column indices, four of two values
-    // (6 memory instructions per tile where loads of single entries take 16).  Granules past the end
-    // of the arrays are clamped to the last one; no row reads those tile slots.
+    // The col and val tiles of a group start at the 128-byte lines that hold its first entry, so that
+    // every lane loads 16 aligned bytes at a time and no two loads of a wavefront share a line: two loads of four column indices, four of two values
+    // (6 memory instructions per tile where loads of single entries take 16), with the non-temporal
+    // hint: the entries are read once per product and should not push x out of the caches (3 % on
+    // the 256^3 Laplacian).  Granules past the end of the arrays are clamped to the last one; no row
+    // reads those tile slots.
     auto issue_colval = [&](RP s_lo, i4v (&cj)[2], d2v (&vj)[4]) {
         const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             RP j = ac + u * 256 + 4 * lane;
             j = j < last4 ? j : last4;
-            cj[u] = *reinterpret_cast<const i4v *>(col + j);
+            cj[u] = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(col + j));
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             RP j = av + u * 128 + 2 * lane;
             j = j < last2 ? j : last2;
-            vj[u] = *reinterpret_cast<const d2v *>(val + j);
+            vj[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + j));
         }
     };
     auto step = [&](int64_t i, i4v (&c_c)[2], d2v (&v_c)[4], i4v (&c_n)[2], d2v (&v_n)[4], RP &lo_c,
