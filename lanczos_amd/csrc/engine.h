@@ -34,6 +34,7 @@ struct Engine {
     // what the matrix upload took (host arrays page-locked around the copies unless LANCZOS_HIP_PIN_UPLOAD=0)
     double upload_sec = 0.0, upload_bytes = 0.0;
     bool upload_pinned = false;
+    char upload_pin_note[48] = "";  // "ok", "off", or the error the registration was refused with
     // device memory
     void *d_rp = nullptr;  // int32 or int64 row offsets
     bool rp64 = false;

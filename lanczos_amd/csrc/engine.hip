@@ -220,8 +220,11 @@ int Engine::setup_device(const lanczos_hip_options &opt, int64_t n_, int64_t n_e
 // registration is refused the copy goes through the runtime's pageable path instead.
 struct HostPin {
     void *ptr = nullptr;
+    hipError_t why = hipSuccess;  // what the registration answered when it was refused
     HostPin(const void *p, size_t bytes, bool enable) {
-        if (enable && bytes && hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess)
+        if (!enable || !bytes) return;
+        why = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault);
+        if (why == hipSuccess)
             ptr = const_cast<void *>(p);
         else
             (void)hipGetLastError();
@@ -241,6 +244,8 @@ int Engine::upload_crs(const int64_t *rp, const int64_t *ci, const double *va) {
     HostPin pin_va(va, sizeof(double) * (size_t)nnz, pin), pin_ci(ci, sizeof(int64_t) * (size_t)nnz, pin),
         pin_rp(rp, sizeof(int64_t) * (size_t)(n + 1), pin);
     upload_pinned = pin_va.ptr != nullptr || nnz == 0;
+    snprintf(upload_pin_note, sizeof(upload_pin_note), "%s",
+             !pin ? "off" : (pin_va.why == hipSuccess ? "ok" : hipGetErrorName(pin_va.why)));
     const int64_t chunk = (int64_t)1 << 26;  // 512 MiB of int64 per piece
     int64_t *stage = nullptr;
     HIP_TRY(hipMalloc(&stage, sizeof(int64_t) * std::min(chunk, std::max(nnz, n + 1))));

@@ -148,8 +148,8 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
             goto cleanup;
         }
     time_init = now_sec() - t_start;
-    fprintf(stderr, "[INIT] name=upload sec=%.6f bytes=%.0f GBps=%.2f pinned=%d\n", e->upload_sec, e->upload_bytes,
-            e->upload_sec > 0 ? e->upload_bytes / e->upload_sec / 1e9 : 0.0, (int)e->upload_pinned);
+    fprintf(stderr, "[INIT] name=upload sec=%.6f bytes=%.0f GBps=%.2f pinned=%d detail_ref=%s\n", e->upload_sec, e->upload_bytes,
+            e->upload_sec > 0 ? e->upload_bytes / e->upload_sec / 1e9 : 0.0, (int)e->upload_pinned, e->upload_pin_note);
     fprintf(stderr, "[INIT] name=total_wall sec=%.6f\n", time_init);
     fprintf(stderr, "[INIT] name=spmv_kernel detail_ref=%s\n", e->spmv_name);
 
