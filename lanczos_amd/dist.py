@@ -226,6 +226,9 @@ class DistLanczos:
 
     def __init__(self, comm: Comm, torch, device, plan: SlabPlan, bounds, max_iter: int, make_engine,
                  reorth: str = "full", interior=None):
+        if reorth == "mgs":
+            raise ValueError("row-partitioned runs take the blocked orders (full, full2, cuda_compat, selective, none): "
+                             "one basis vector at a time would cost one reduction over ranks per vector")
         self.comm, self.torch, self.device = comm, torch, device
         self.plan, self.bounds, self.max_iter, self.reorth = plan, bounds, max_iter, reorth
         self.rank, self.world = comm.rank, comm.world

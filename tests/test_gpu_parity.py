@@ -704,6 +704,21 @@ def test_lanczos_takes_a_custom_matvec_plugin(gpu):
         assert rel_err(alpha[:20], oo.alpha[:20]) < 1e-11 and rel_err(beta[:20], oo.beta[:20]) < 1e-11, reorth
 
 
+def test_c_program_with_a_matrix_free_plugin(gpu):
+    """lanczos_amd/bin/plugin_demo: a C program whose only operator is a function (2-D Laplacian applied
+    matrix-free) calls lanczos() of liblanczos_host; values against the oracle on the assembled matrix."""
+    exe = os.path.join(ROOT, "lanczos_amd", "bin", "plugin_demo")
+    a = la.synth_laplacian(2, 80)
+    v0 = la.gaussian_fill(123456789, 0, a.dimension)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 3, 61, 0.0)
+    p = subprocess.run([exe, "80", "3", "61"], capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, LANCZOS_HIP_QUIET="1"))
+    assert p.returncode == 0, p.stderr[-1000:]
+    assert "operator calls\t60" in p.stdout
+    eig = [float(ln.split("\t")[-1]) for ln in p.stdout.splitlines() if ln.startswith("eigenvalue")]
+    assert len(eig) == 3 and np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12   # printed at %.12f
+
+
 def test_driver_binary_on_triplet_file(gpu, tmp_path):
     """main -> read_mat_coo_incremental -> convert_from_coo(swap=1) -> lanczos_hip_crs."""
     n = 10000
