@@ -131,7 +131,10 @@ struct lanczos_hip_multi {
     std::vector<double *> basis, x_ext, red;          // device memory owned here
     std::vector<int64_t> ld, base, halo_lo, halo_hi, send_lo, send_hi, in_lo, in_hi;
     int64_t pad = 0;                                  // all-gather: entries per slab in x_ext
-    std::vector<ncclComm_t> comm;
+    std::vector<ncclComm_t> comm;    // all-reduce / all-gather, on the compute streams
+    std::vector<ncclComm_t> xcomm;   // halo sends and receives, on the exchange streams: a communicator of
+                                     // their own, so that operations issued on two streams of one device
+                                     // never share a communicator
     double **d_red_ptrs = nullptr;                    // loopback: the slabs' reduction buffers
     lanczos_hip_omega *omega = nullptr;               // selective mode: one tracker decides for all slabs
     double *h_sel = nullptr;                          // pinned: alpha_k, |w|^2 for that decision
@@ -165,6 +168,8 @@ lanczos_hip_multi::~lanczos_hip_multi() {
     }
     for (size_t p = 0; p < comm.size(); ++p)
         if (comm[p] && rccl()) (void)rccl()->CommDestroy(comm[p]);
+    for (size_t p = 0; p < xcomm.size(); ++p)
+        if (xcomm[p] && rccl()) (void)rccl()->CommDestroy(xcomm[p]);
     for (size_t p = 0; p < dev.size(); ++p) {
         (void)hipSetDevice(dev[p]);
         if (p < basis.size()) (void)hipFree(basis[p]);
@@ -348,6 +353,10 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
         if (!rccl()) return lz::fail("lanczos_hip_multi_create: librccl.so.1 could not be opened (%s)", dlerror());
         comm.assign((size_t)P, nullptr);
         M_RCCL(rccl()->CommInitAll(comm.data(), P, dev.data()));
+        if (halo && P > 1) {
+            xcomm.assign((size_t)P, nullptr);
+            M_RCCL(rccl()->CommInitAll(xcomm.data(), P, dev.data()));
+        }
     }
     if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) {
         omega = lanczos_hip_omega_create(max_iter);
@@ -458,15 +467,15 @@ int lanczos_hip_multi::exchange_begin() {
         const int64_t nl = bounds[(size_t)p + 1] - bounds[(size_t)p];
         double *x = vec(p, k);
         if (st == ncclSuccess && send_lo[(size_t)p])
-            st = rccl()->Send(x, (size_t)send_lo[(size_t)p], ncclDouble, p - 1, comm[(size_t)p], cstream[(size_t)p]);
+            st = rccl()->Send(x, (size_t)send_lo[(size_t)p], ncclDouble, p - 1, xcomm[(size_t)p], cstream[(size_t)p]);
         if (st == ncclSuccess && halo_hi[(size_t)p])
             st = rccl()->Recv(x + base[(size_t)p] + halo_lo[(size_t)p], (size_t)halo_hi[(size_t)p], ncclDouble, p + 1,
-                              comm[(size_t)p], cstream[(size_t)p]);
+                              xcomm[(size_t)p], cstream[(size_t)p]);
         if (st == ncclSuccess && send_hi[(size_t)p])
-            st = rccl()->Send(x + (nl - send_hi[(size_t)p]), (size_t)send_hi[(size_t)p], ncclDouble, p + 1, comm[(size_t)p],
+            st = rccl()->Send(x + (nl - send_hi[(size_t)p]), (size_t)send_hi[(size_t)p], ncclDouble, p + 1, xcomm[(size_t)p],
                               cstream[(size_t)p]);
         if (st == ncclSuccess && halo_lo[(size_t)p])
-            st = rccl()->Recv(x + base[(size_t)p], (size_t)halo_lo[(size_t)p], ncclDouble, p - 1, comm[(size_t)p],
+            st = rccl()->Recv(x + base[(size_t)p], (size_t)halo_lo[(size_t)p], ncclDouble, p - 1, xcomm[(size_t)p],
                               cstream[(size_t)p]);
     }
     if (st != ncclSuccess) {
