@@ -250,6 +250,8 @@ class DistLanczos:
         self.interior = interior if (interior and self.in_place and getattr(self.engine, "can_overlap", False)) else None
         self.k = 0
         self.reorth_steps = 0
+        self._views = {}
+        self.red1, self.red2 = self.red[:1], self.red[:2]
         # no reorthogonalisation: unnormalised basis, one reduction of two doubles per iteration
         self.lazy = reorth == "none" and hasattr(self.engine, "phase_recur_lazy")
         self._closed_k = 0
@@ -297,10 +299,16 @@ class DistLanczos:
             self.engine.export_vector(self.k, x[:n])
         if self.world == 1:
             return []
-        send_lo = x[:self.send_lo] if self.send_lo else None
-        send_hi = x[n - self.send_hi:n] if self.send_hi else None
-        recv_lo = x[base:base + p.halo_lo] if p.halo_lo else None
-        recv_hi = x[base + p.halo_lo:base + p.halo_lo + p.halo_hi] if p.halo_hi else None
+        # the four views of a basis slot never change: built once per slot
+        slot = (self.k % 3 if self.nvec == 3 else self.k) if self.in_place else -1
+        views = self._views.get(slot)
+        if views is None:
+            views = (x[:self.send_lo] if self.send_lo else None,
+                     x[base:base + p.halo_lo] if p.halo_lo else None,
+                     x[n - self.send_hi:n] if self.send_hi else None,
+                     x[base + p.halo_lo:base + p.halo_lo + p.halo_hi] if p.halo_hi else None)
+            self._views[slot] = views
+        send_lo, recv_lo, send_hi, recv_hi = views
         works = self.comm.neighbour_exchange_start(send_lo, recv_lo, send_hi, recv_hi)
         if start_only:
             return works
@@ -319,11 +327,11 @@ class DistLanczos:
             self.exchange()
             e.phase_spmv(red)
         if self.lazy:
-            self.comm.all_reduce_sum(red[:2])             # u_k . A u_k and |u_k|^2 together
+            self.comm.all_reduce_sum(self.red2)           # u_k . A u_k and |u_k|^2 together
             e.phase_recur_lazy(red)
             self.k += 1
             return
-        self.comm.all_reduce_sum(red[:1])                 # alpha
+        self.comm.all_reduce_sum(self.red1)               # alpha
         if self.reorth == "selective":
             self.ab[0:1].copy_(red[:1])
         n_red, is_norm = e.phase_recur(red)
