@@ -83,7 +83,9 @@ typedef struct crs {
  *                       src/lanczos_cuda.c:395)
  *   LANCZOS_HIP_DEVICE  HIP device ordinal (default: current device)
  *   LANCZOS_HIP_NGPU    number of GPUs: above 1 the matrix is row-partitioned over devices 0..N-1 of
- *                       this node (lanczos_hip_multi_create below; no checkpoints or eigenvectors there)
+ *                       this node (lanczos_hip_multi_create below; no checkpoints or eigenvectors there);
+ *                       LANCZOS_HIP_MULTI_LOOPBACK=1 keeps the slabs on one GPU, LANCZOS_HIP_MULTI_FORCE=1 takes
+ *                       the row-slab path even with one slab (both for rehearsal on a one-GPU machine)
  *   LANCZOS_HIP_QUIET   1 suppresses the per-iteration stdout lines
  *   LANCZOS_HIP_WINDOW  iterations enqueued ahead of the one the host is looking at (default 4)
  *   LANCZOS_HIP_PROFILE 0 drops the per-kernel events behind the [TOTAL] lines (default 1)

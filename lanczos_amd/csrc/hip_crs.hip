@@ -89,6 +89,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     lanczos_hip_multi *mg = nullptr;  // several GPUs: e is then the engine of slab 0, owned by mg
     const int ngpu = env_int("LANCZOS_HIP_NGPU", 1);
     const bool loopback = env_int("LANCZOS_HIP_MULTI_LOOPBACK", 0) != 0;
+    const bool force_slabs = env_int("LANCZOS_HIP_MULTI_FORCE", 0) != 0;  // the row-slab path with one slab (rehearsal)
     std::vector<hipEvent_t> done((size_t)window, nullptr);
     std::vector<double> a((size_t)max_iter, 0.0), b((size_t)max_iter, 0.0), last((size_t)nth_eig, 0.0);
     const int total = max_iter - 1;
@@ -102,7 +103,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
     const char *resume_path = getenv("LANCZOS_HIP_RESUME");
 
-    if (mat && (ngpu > 1 || loopback)) {
+    if (mat && (ngpu > 1 || loopback || force_slabs)) {
         if ((resume_path && *resume_path) || (ckpt_path && *ckpt_path && ckpt_every > 0) || want_vectors) {
             lz::fail("LANCZOS_HIP_NGPU: checkpoints and eigenvectors need the whole basis on one GPU");
             goto cleanup;

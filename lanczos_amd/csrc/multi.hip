@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <new>
@@ -351,12 +352,24 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
         M_HIP(hipMemcpy(d_red_ptrs, red.data(), sizeof(double *) * (size_t)P, hipMemcpyHostToDevice));
     } else {
         if (!rccl()) return lz::fail("lanczos_hip_multi_create: librccl.so.1 could not be opened (%s)", dlerror());
+        // RCCL prints a version banner on stdout when a process makes its first communicator; stdout
+        // carries the solver's own lines (src/lanczos.c:134-138), so the banner goes to stderr
+        fflush(stdout);
+        const int keep_out = dup(1);
+        if (keep_out >= 0) (void)dup2(2, 1);
         comm.assign((size_t)P, nullptr);
-        M_RCCL(rccl()->CommInitAll(comm.data(), P, dev.data()));
-        if (halo && P > 1) {
+        ncclResult_t st = rccl()->CommInitAll(comm.data(), P, dev.data());
+        if (st == ncclSuccess && halo && P > 1) {
             xcomm.assign((size_t)P, nullptr);
-            M_RCCL(rccl()->CommInitAll(xcomm.data(), P, dev.data()));
+            st = rccl()->CommInitAll(xcomm.data(), P, dev.data());
         }
+        fflush(stdout);
+        if (keep_out >= 0) {
+            (void)dup2(keep_out, 1);
+            close(keep_out);
+        }
+        if (st != ncclSuccess)
+            return lz::fail("RCCL API failed: ncclCommInitAll over %d devices: %s (%d)", P, rccl()->GetErrorString(st), (int)st);
     }
     if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) {
         omega = lanczos_hip_omega_create(max_iter);

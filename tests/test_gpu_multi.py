@@ -151,6 +151,10 @@ def test_dropin_honours_ngpu(gpu):
                                              "LANCZOS_HIP_JSON": "1"})
     rec = json.loads([ln for ln in err.splitlines() if ln.startswith('{"lanczos_hip"')][0])["lanczos_hip"]
     assert res["rc"] == 0 and rec["exit_kind"] == ob.exit_kind == 1 and rec["exit_step"] == ob.steps
+    # RCCL with one slab behind the drop-in: its version banner must not land among the solver's stdout lines
+    res, out, err = _dropin(a, 4, 31, 0.0, {"LANCZOS_HIP_NGPU": "1", "LANCZOS_HIP_MULTI_LOOPBACK": "0",
+                                            "LANCZOS_HIP_MULTI_FORCE": "1"})
+    assert res["rc"] == 0 and "transport=rccl" in err and "RCCL version" not in out
     # asking for more GPUs than there are fails cleanly with EXIT_FAILURE and a message
     import torch
     res, out, _ = _dropin(a, 4, 21, 0.0, {"LANCZOS_HIP_NGPU": str(torch.cuda.device_count() + 1)})
