@@ -315,6 +315,7 @@ extern "C" {
 int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, const int64_t *row_head_indexes,
                              const int64_t *column_index, const double *values, int max_steps,
                              const lanczos_hip_options *opt_in) {
+    return lz::guarded("lanczos_hip_block_create", [&]() -> int {
     if (!out) return lz::fail("lanczos_hip_block_create: NULL handle");
     *out = nullptr;
     if (max_steps < 1) return lz::fail("lanczos_hip_block_create: max_steps must be >= 1");
@@ -339,6 +340,7 @@ int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, co
     }
     *out = reinterpret_cast<lanczos_hip_block *>(b);
     return 0;
+    });
 }
 
 void lanczos_hip_block_destroy(lanczos_hip_block *b) { delete B(b); }
@@ -349,15 +351,19 @@ int lanczos_hip_block_set_start(lanczos_hip_block *b, const double *x0_host) {
 }
 
 int lanczos_hip_block_set_start_seed(lanczos_hip_block *b, uint64_t seed) {
+    return lz::guarded("lanczos_hip_block_set_start_seed", [&]() -> int {
     if (!b) return lz::fail("lanczos_hip_block_set_start_seed: NULL handle");
     std::vector<double> x((size_t)B(b)->n * kW);
     lanczos_hip_gaussian_fill(seed, 0, (int64_t)x.size(), x.data());
     return B(b)->set_start(x.data());
+    });
 }
 
 int lanczos_hip_block_run(lanczos_hip_block *b, int steps) {
+    return lz::guarded("lanczos_hip_block_run", [&]() -> int {
     if (!b || steps < 0) return lz::fail("lanczos_hip_block_run: bad argument");
     return B(b)->run(steps);
+    });
 }
 
 int lanczos_hip_block_steps(const lanczos_hip_block *b) {
@@ -365,6 +371,7 @@ int lanczos_hip_block_steps(const lanczos_hip_block *b) {
 }
 
 int lanczos_hip_block_tmatrix(lanczos_hip_block *bh, int steps, double *a_out, double *b_out) {
+    return lz::guarded("lanczos_hip_block_tmatrix", [&]() -> int {
     BlockEngine *b = B(bh);
     if (!b || steps < 0 || steps > b->steps) return lz::fail("lanczos_hip_block_tmatrix: bad argument");
     HIP_TRY(hipSetDevice(b->base->device));
@@ -372,9 +379,11 @@ int lanczos_hip_block_tmatrix(lanczos_hip_block *bh, int steps, double *a_out, d
     if (steps && a_out) HIP_TRY(hipMemcpy(a_out, b->d_TA, sizeof(double) * 256 * steps, hipMemcpyDeviceToHost));
     if (steps && b_out) HIP_TRY(hipMemcpy(b_out, b->d_TB, sizeof(double) * 256 * steps, hipMemcpyDeviceToHost));
     return 0;
+    });
 }
 
 int lanczos_hip_block_ritz(lanczos_hip_block *bh, int steps, int nth, double *eig_out) {
+    return lz::guarded("lanczos_hip_block_ritz", [&]() -> int {
     BlockEngine *b = B(bh);
     if (!b || !eig_out || nth < 1 || steps < 1 || steps > b->steps)
         return lz::fail("lanczos_hip_block_ritz: bad argument");
@@ -396,6 +405,7 @@ int lanczos_hip_block_ritz(lanczos_hip_block *bh, int steps, int nth, double *ei
         return lz::fail("lanczos_hip_block_ritz: eigen-solve failed");
     for (int i = N; i < nth; ++i) eig_out[i] = 0.0;
     return 0;
+    });
 }
 
 int lanczos_hip_block_get_block(lanczos_hip_block *bh, int t, double *out_host) {

@@ -100,6 +100,7 @@ int copy_in(FILE *fp, double *dev, size_t count, std::vector<double> &stage) {
 }  // namespace
 
 extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *path) {
+    return lz::guarded("lanczos_hip_checkpoint_save", [&]() -> int {
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !path) return lz::fail("lanczos_hip_checkpoint_save: NULL argument");
     if (!e->started) return lz::fail("lanczos_hip_checkpoint_save: no run to save");
@@ -150,9 +151,11 @@ extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *p
     bad = (fclose(fp) != 0) || bad;
     if (bad) return lz::fail("lanczos_hip_checkpoint_save: write to %s failed", path);
     return 0;
+    });
 }
 
 extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *path) {
+    return lz::guarded("lanczos_hip_checkpoint_load", [&]() -> int {
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !path) return lz::fail("lanczos_hip_checkpoint_load: NULL argument");
     if (e->slab) return lz::fail("lanczos_hip_checkpoint_load: not available on a row-partitioned engine");
@@ -238,4 +241,5 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     }
     e->started = true;
     return 0;
+    });
 }

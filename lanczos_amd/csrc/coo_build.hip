@@ -190,16 +190,19 @@ int Engine::create_from_coo(Engine **out, const Mat_Coo *coo, int swap, int max_
 
 extern "C" int lanczos_hip_create_from_coo(lanczos_hip_engine **out, const Mat_Coo *mat_coo, int swap_row_column,
                                            int max_iter, const lanczos_hip_options *opt) {
+    return lz::guarded("lanczos_hip_create_from_coo", [&]() -> int {
     if (!out) return lz::fail("lanczos_hip_create_from_coo: NULL out");
     lz::Engine *e = nullptr;
     int rc = lz::Engine::create_from_coo(&e, mat_coo, swap_row_column, max_iter, opt);
     *out = reinterpret_cast<lanczos_hip_engine *>(e);
     return rc;
+    });
 }
 
 // Test hook: the device CRS widened back to the layout of Mat_Crs.
 extern "C" int lanczos_hip_download_crs(lanczos_hip_engine *eh, int64_t *row_head_indexes, int64_t *column_index,
                                         double *values) {
+    return lz::guarded("lanczos_hip_download_crs", [&]() -> int {
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !row_head_indexes) return lz::fail("lanczos_hip_download_crs: NULL argument");
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
@@ -221,4 +224,5 @@ extern "C" int lanczos_hip_download_crs(lanczos_hip_engine *eh, int64_t *row_hea
         st = hipMemcpy(values, e->d_val, 8 * e->nnz, hipMemcpyDeviceToHost);
     if (st != hipSuccess) return lz::fail("lanczos_hip_download_crs: %s", hipGetErrorString(st));
     return 0;
+    });
 }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <exception>
+#include <new>
 #include <vector>
 
 #include "../../include/lanczos_hip.h"
@@ -13,6 +15,21 @@ constexpr int kMaxDotsSegment = 1024;  // basis vectors per k_dots launch (32 Ki
 
 int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 const char *last_error();
+
+// The body of an extern "C" entry point: no C++ exception (a failed host allocation above all) may
+// cross the C boundary; it becomes the usual message + EXIT_FAILURE.
+template <class F>
+int guarded(const char *what, F &&body) noexcept {
+    try {
+        return body();
+    } catch (const std::bad_alloc &) {
+        return fail("%s: out of host memory", what);
+    } catch (const std::exception &ex) {
+        return fail("%s: %s", what, ex.what());
+    } catch (...) {
+        return fail("%s: unknown C++ exception", what);
+    }
+}
 
 struct Engine {
     // geometry

@@ -1158,11 +1158,13 @@ extern "C" {
 int lanczos_hip_create(lanczos_hip_engine **out, int64_t n, int64_t nnz, const int64_t *row_head_indexes,
                        const int64_t *column_index, const double *values, int max_iter,
                        const lanczos_hip_options *opt) {
+    return lz::guarded("lanczos_hip_create", [&]() -> int {
     if (!out) return lz::fail("lanczos_hip_create: NULL out");
     Engine *e = nullptr;
     int rc = Engine::create(&e, n, nnz, row_head_indexes, column_index, values, max_iter, opt);
     *out = reinterpret_cast<lanczos_hip_engine *>(e);
     return rc;
+    });
 }
 
 void lanczos_hip_destroy(lanczos_hip_engine *e) { delete E(e); }
@@ -1178,18 +1180,22 @@ int lanczos_hip_set_start_scaled(lanczos_hip_engine *e, const double *v0_host, d
 }
 
 int lanczos_hip_set_start_seed(lanczos_hip_engine *e, uint64_t seed) {
+    return lz::guarded("lanczos_hip_set_start_seed", [&]() -> int {
     if (!e) return lz::fail("lanczos_hip_set_start_seed: NULL engine");
     Engine *g = E(e);
     if (g->slab) return lz::fail("lanczos_hip_set_start_seed: row-partitioned engines need a global norm; use lanczos_hip_gaussian_fill + lanczos_hip_set_start_scaled");
     std::vector<double> v((size_t)g->n);
     lanczos_hip_gaussian_fill(seed, g->row_begin, g->n, v.data());
     return g->set_start(v.data(), true, 1.0);
+    });
 }
 
 int lanczos_hip_run(lanczos_hip_engine *e, int steps, double *alpha_out, double *beta_out) {
+    return lz::guarded("lanczos_hip_run", [&]() -> int {
     if (!e) return lz::fail("lanczos_hip_run: NULL engine");
     if (E(e)->slab) return lz::fail("lanczos_hip_run: row-partitioned engines are driven phase by phase");
     return E(e)->run(steps, alpha_out, beta_out);
+    });
 }
 
 int lanczos_hip_set_operator(lanczos_hip_engine *e, lanczos_hip_matvec_fn *matvec, const void *mat) {
@@ -1202,8 +1208,10 @@ int lanczos_hip_iterations(const lanczos_hip_engine *e) { return e ? E(e)->k : 0
 int lanczos_hip_reorth_steps(const lanczos_hip_engine *e) { return e ? E(e)->reorth_steps : 0; }
 
 int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host) {
+    return lz::guarded("lanczos_hip_spmv", [&]() -> int {
     if (!e) return lz::fail("lanczos_hip_spmv: NULL engine");
     return E(e)->spmv_host(x_host, y_host);
+    });
 }
 
 int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host) {
@@ -1245,6 +1253,7 @@ void lanczos_hip_profile_reset(lanczos_hip_engine *e) {
 
 int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *eig, double *vectors_host,
                              double *residual_est) {
+    return lz::guarded("lanczos_hip_ritz_vectors", [&]() -> int {
     if (!eh || !eig || steps < 1 || m < 1) return lz::fail("lanczos_hip_ritz_vectors: bad argument");
     Engine *e = E(eh);
     if (e->reorth == LANCZOS_HIP_REORTH_NONE || e->slab)
@@ -1276,11 +1285,14 @@ int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *e
         rc = lz::fail("lanczos_hip_ritz_vectors: copy to the host failed");
     (void)hipFree(d_y);
     return rc;
+    });
 }
 
 int lanczos_hip_restart(lanczos_hip_engine *e, int keep, const double *coef_host, double last_coupling) {
+    return lz::guarded("lanczos_hip_restart", [&]() -> int {
     if (!e) return lz::fail("lanczos_hip_restart: NULL handle");
     return E(e)->restart(keep, coef_host, last_coupling);
+    });
 }
 
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e) { return e ? E(e)->spmv_name : ""; }

@@ -284,13 +284,17 @@ cleanup:
 
 extern "C" int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[], int nth_eig,
                                int max_iter, double threshold) {
+    return lz::guarded("lanczos_hip_crs", [&]() -> int {
     if (mat == NULL) return EXIT_FAILURE;  // src/lanczos_cuda.c:316-318
     return solve(mat, nullptr, nullptr, mat->dimension, eigenvalues, eigenvectors, nth_eig, max_iter, threshold);
+    });
 }
 
 extern "C" int lanczos_hip_operator(lanczos_hip_matvec_fn *matvec, const void *mat, size_t dimension,
                                     double eigenvalues[], double *eigenvectors[], int nth_eig, int max_iter,
                                     double threshold) {
+    return lz::guarded("lanczos_hip_operator", [&]() -> int {
     if (matvec == NULL) return EXIT_FAILURE;
     return solve(nullptr, matvec, mat, dimension, eigenvalues, eigenvectors, nth_eig, max_iter, threshold);
+    });
 }

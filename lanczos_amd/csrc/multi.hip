@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -48,16 +49,12 @@ struct Rccl {
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Rccl *rccl() {
-    static Rccl r;
-    static bool tried = false;
-    if (tried) return r.lib ? &r : nullptr;
-    tried = true;
+bool load_rccl(Rccl &r) {
     for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (r.lib) break;
     }
-    if (!r.lib) return nullptr;
+    if (!r.lib) return false;
     bool ok = true;
     auto sym = [&](const char *n) {
         void *p = dlsym(r.lib, n);
@@ -76,9 +73,16 @@ Rccl *rccl() {
     if (!ok) {
         dlclose(r.lib);
         r.lib = nullptr;
-        return nullptr;
     }
-    return &r;
+    return ok;
+}
+
+// the library's entry points, or nullptr when librccl cannot be opened (looked up once, thread safe)
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] { load_rccl(r); });
+    return r.lib ? &r : nullptr;
 }
 
 #define M_HIP(call)                                                                                   \
@@ -628,6 +632,7 @@ extern "C" {
 int lanczos_hip_multi_create(lanczos_hip_multi **out, int ngpu, const int *devices, int64_t n, int64_t nnz,
                              const int64_t *row_head_indexes, const int64_t *column_index, const double *values,
                              int max_iter, const lanczos_hip_options *opt, int flags) {
+    return lz::guarded("lanczos_hip_multi_create", [&]() -> int {
     if (!out) return lz::fail("lanczos_hip_multi_create: NULL out");
     *out = nullptr;
     lanczos_hip_multi *m = new (std::nothrow) lanczos_hip_multi();
@@ -639,16 +644,20 @@ int lanczos_hip_multi_create(lanczos_hip_multi **out, int ngpu, const int *devic
     }
     *out = m;
     return 0;
+    });
 }
 
 void lanczos_hip_multi_destroy(lanczos_hip_multi *m) { delete m; }
 
 int lanczos_hip_multi_set_start(lanczos_hip_multi *m, const double *v0_host) {
+    return lz::guarded("lanczos_hip_multi_set_start", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_set_start: NULL handle");
     return m->set_start(v0_host);
+    });
 }
 
 int lanczos_hip_multi_set_start_seed(lanczos_hip_multi *m, uint64_t seed) {
+    return lz::guarded("lanczos_hip_multi_set_start_seed", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_set_start_seed: NULL handle");
     std::vector<double> v;
     try {
@@ -658,16 +667,21 @@ int lanczos_hip_multi_set_start_seed(lanczos_hip_multi *m, uint64_t seed) {
     }
     lanczos_hip_gaussian_fill(seed, 0, m->n, v.data());
     return m->set_start(v.data());
+    });
 }
 
 int lanczos_hip_multi_run(lanczos_hip_multi *m, int steps, double *alpha_out, double *beta_out) {
+    return lz::guarded("lanczos_hip_multi_run", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_run: NULL handle");
     return m->run(steps, alpha_out, beta_out);
+    });
 }
 
 int lanczos_hip_multi_step(lanczos_hip_multi *m) {
+    return lz::guarded("lanczos_hip_multi_step", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_step: NULL handle");
     return m->step(true);
+    });
 }
 
 lanczos_hip_engine *lanczos_hip_multi_engine(lanczos_hip_multi *m, int slab) {

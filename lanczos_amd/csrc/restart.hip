@@ -15,6 +15,7 @@
 extern "C" int lanczos_hip_thick_restart(lanczos_hip_engine *eh, int nth, int keep, int max_cycles, double tol,
                                          double *eig_out, double *resid_out, double *vectors_host,
                                          int *cycles_out, int *products_out) {
+    return lz::guarded("lanczos_hip_thick_restart", [&]() -> int {
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !eig_out || nth < 1 || max_cycles < 1) return lz::fail("lanczos_hip_thick_restart: bad argument");
     if (e->slab) return lz::fail("lanczos_hip_thick_restart: not available on a row-partitioned engine");
@@ -81,4 +82,5 @@ extern "C" int lanczos_hip_thick_restart(lanczos_hip_engine *eh, int nth, int ke
         if (rc) return rc;
     }
     return 0;
+    });
 }
