@@ -163,7 +163,7 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     import lanczos_amd as la
     import oracle
     if kind == "lap2d":
-        full = la.synth_laplacian(2, 30)
+        full = la.synth_laplacian(2, 30 if world <= 3 else 64)   # 512-row slabs for 8 ranks: halos stay below half a slab
     else:
         full = la.synth_random_symmetric(700, 6, 11)
     n = full.dimension
@@ -209,6 +209,8 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     (2, "lap2d", "auto+", "full", "halo", 25),
     (3, "lap2d", "auto+", "none", "halo", 25),
     (2, "random", "auto+", "full", "allgather", 25),
+    (8, "lap2d", "auto+", "full", "halo", 25),        # the rank count of a whole node: 112-row slabs, 30-entry halos
+    (8, "random", "auto", "none", "allgather", 25),
 ])
 def test_partitioned_run_matches_single_process(world, kind, mode, reorth, expect_mode, steps):
     ctx = mp.get_context("spawn")
