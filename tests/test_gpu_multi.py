@@ -83,6 +83,21 @@ def test_loopback_forced_allgather_and_unsplit_product(gpu, monkeypatch):
         assert np.array_equal(ra, np.concatenate([pa, qa]))
 
 
+def test_loopback_eight_slabs(gpu):
+    """The slab count of a whole node: 4096-row slabs of a 32^3 Laplacian whose 1024-entry halos are just
+    within half a slab (halo form), and the 32-row slabs of a 16 x 16 grid, too thin for it (all-gather form)."""
+    for a, want_halo in ((la.synth_laplacian(3, 32), 1), (la.synth_laplacian(2, 16), 0)):
+        v0 = la.gaussian_fill(9, 0, a.dimension)
+        for reorth in ("full", "none"):
+            a1, b1 = single(a, v0, 30, reorth)
+            with la.MultiEngine(a, 31, 8, reorth=reorth, loopback=True) as m:
+                assert m.info()["halo"] == want_halo
+                m.set_start(v0)
+                a2, b2 = m.run(30)
+            cmp = 20 if reorth == "none" else 30
+            assert rel_err(a2[:cmp], a1[:cmp]) < 1e-11 and rel_err(b2[:cmp], b1[:cmp]) < 1e-11, (reorth, want_halo)
+
+
 def test_rccl_transport_with_one_slab(gpu):
     """ncclCommInitAll over the one device of this box: every collective of an iteration goes through
     RCCL with world size 1; the sequences are the single engine's to rounding (1e-12 relative)."""
