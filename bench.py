@@ -62,6 +62,9 @@ def parse_args():
                          "resident: 1200 vectors of the 256^3 problem are 161 GB); 0 skips it")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the row-partitioned code path even with one rank (rehearsal)")
+    ap.add_argument("--no-in-process", action="store_true",
+                    help="multi-rank runs: skip the section in which rank 0 alone drives all GPUs through the "
+                         "library's own RCCL calls")
     ap.add_argument("--main-only", action="store_true",
                     help="only the timed region and its warm-up (for profiler passes): no secondary sections")
     ap.add_argument("--cpu-steps", type=int, default=0, help="CPU sample length; 0 = size it for ~15 s")

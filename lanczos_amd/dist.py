@@ -735,6 +735,38 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None
                 "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
             }
 
+    def sec_in_process():
+        # The other multi-GPU path on the same hardware: ONE process (rank 0) drives all the GPUs of the
+        # node through the library's own RCCL calls (lanczos_hip_multi_*, what LANCZOS_HIP_NGPU gives the
+        # C driver), while the other ranks wait on the host.  Same matrix, start vector and step counts as
+        # the primary figure.
+        gl = dist.new_group(backend="gloo")          # a host-side barrier: no kernel spins on the waiting GPUs
+        if rank == 0:
+            try:
+                full = la.synth_laplacian(d, N)
+                res = {}
+                for mode, steps_m, warm in ((args.reorth, K, W), ("none", steps2, 5)):
+                    with la.MultiEngine(full, max(steps_m, warm) + 1, world, reorth=mode) as m:
+                        m.set_start_seed(123456789)
+                        m.run(warm)
+                        m.set_start_seed(123456789)
+                        t0 = time.perf_counter()
+                        a_m, b_m = m.run(steps_m)     # returns when every slab's stream has drained
+                        dt_m = time.perf_counter() - t0
+                        info = m.info()
+                    res[mode] = {"steps": steps_m, "iters_per_s": steps_m / dt_m, "ms_per_step": dt_m / steps_m * 1e3,
+                                 "exchange": "halo" if info["halo"] else "allgather",
+                                 "exchange_overlapped_with_product": bool(info["overlapped"])}
+                    if mode == args.reorth:
+                        r_m = la.ritz_values(a_m, b_m, steps_m, 4)
+                        res[mode]["ritz_rel_diff_vs_primary"] = float(np.max(np.abs(r_m - ritz) / np.abs(ritz)))
+                out["in_process_rccl"] = dict(res, gpus=world, note="one host process, ncclCommInitAll over the "
+                                              "node's GPUs; the other ranks idle on a host barrier")
+            except Exception as exc:  # noqa: BLE001
+                out["in_process_rccl"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            torch.cuda.set_device(local_rank)
+        dist.barrier(group=gl)
+
     section("spmv_vector_step", sec_vector_step)
     if getattr(args, "big_grid", 0) > 0:
         section("strong_scaling_laplacian", sec_big_grid)
@@ -742,6 +774,8 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None
         section("random_symmetric", sec_random)
     if getattr(args, "converge_steps", 0) > 0 and d == 3:
         section("converged_run", sec_converge)
+    if not getattr(args, "no_in_process", False):
+        section("in_process_rccl", sec_in_process)
     state["done"] = True
     timer.cancel()
     dist.barrier()

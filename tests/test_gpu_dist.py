@@ -126,6 +126,9 @@ def test_bench_distributed_code_path_with_one_rank(gpu):
     assert out["n_gpus"] == 1 and out["steps"] == 40 and out["value"] > 0
     assert out["strong_scaling_laplacian"]["iters_per_s"] > 0 and out["random_symmetric"]["iters_per_s"] > 0
     assert out["converged_run"]["steps"] == 60 and out["converged_run"]["seconds"] > 0
+    inproc = out["in_process_rccl"]                    # rank 0 driving the slabs through the library's own RCCL calls
+    assert inproc["gpus"] == 1 and inproc["full"]["iters_per_s"] > 0 and inproc["none"]["iters_per_s"] > 0
+    assert inproc["full"]["ritz_rel_diff_vs_primary"] < 1e-10
     import lanczos_amd as la
     a = la.synth_laplacian(3, 64)
     with la.Engine(a, 41) as e:
