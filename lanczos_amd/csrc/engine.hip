@@ -303,8 +303,17 @@ int Engine::choose_spmv(int requested) {
     if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && max_span > kRowsMaxSpan)
         return fail("lanczos_hip_create: the rows SpMV needs every 64-row group to hold <= %d entries (max %lld)",
                     kRowsMaxSpan, (long long)max_span);
+    // wildly uneven rows: the fullest 64-row group holds 16 times the average
+    const bool uneven = (double)max_span > 16.0 * 64.0 * std::max(mean, 1.0);
+    bool bits_given = false;
     if (const char *s = getenv("LANCZOS_HIP_PANEL_BITS"))
-        if (atoi(s) >= 10 && atoi(s) <= 24) panel_bits = atoi(s);
+        if (atoi(s) >= 10 && atoi(s) <= 24) {
+            panel_bits = atoi(s);
+            bits_given = true;
+        }
+    // narrow panels for power-law graphs: their tiles are small and the workgroups do not sweep in step,
+    // so what a panel's slice of x has to fit is a CU's share of the L2, not the L2
+    if (!bits_given && uneven) panel_bits = 12;
     const bool no_dict = getenv("LANCZOS_HIP_NO_DICT") && atoi(getenv("LANCZOS_HIP_NO_DICT")) != 0;
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO && !no_dict && stats[1] > 0 && 2 * stats[2] > stats[1]) {
         // neighbouring rows hold neighbouring columns: rows are likely to repeat as patterns
@@ -324,8 +333,13 @@ int Engine::choose_spmv(int requested) {
         } else {
             // rows that reach across more of x than the L2s hold (the sampled rows' mean column
             // extent against 16 MiB of doubles, half the L2s): gathers would each fetch a line from memory
+            // With uneven rows the share-of-entries form (below) holds up while x fits the caches behind
+            // the L2s; the tiled form takes over beyond 40 MiB of x (measured on R-MAT graphs: 1.43 against
+            // 1.65 ms at n = 2^22, 8.4 against 5.3 ms at 2^24, 45 against 21 ms at 2^26).
             const double extent = stats[3] ? (double)stats[4] / (double)stats[3] : 0.0;
-            if (extent * 8.0 > 16.0 * 1048576.0 && mean >= 2.0 && max_span <= 64 * 64) {
+            const bool tiled = uneven ? extent * 8.0 > 8.0 * 1048576.0 && 8.0 * (double)n_ext > 40.0 * 1048576.0
+                                      : extent * 8.0 > 16.0 * 1048576.0;
+            if (tiled && mean >= 2.0) {
                 if (int rc = build_panels(panel_bits)) return rc;
                 if (tile_panels > 0) spmv_kind = LANCZOS_HIP_SPMV_PANEL;
             }
@@ -341,9 +355,8 @@ int Engine::choose_spmv(int requested) {
     log2r = 6;
     while (log2r > 0 && mean * (double)(1 << log2r) > 0.9 * kTile) log2r--;
     if (log2r == 1) log2r = 0;
-    // wildly uneven rows (the fullest 64-row group holds 16 times the average): shares of entries
-    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE && requested == LANCZOS_HIP_SPMV_AUTO &&
-        (double)max_span > 16.0 * 64.0 * std::max(mean, 1.0))
+    // uneven rows that the tiled form did not take: shares of entries
+    if (spmv_kind == LANCZOS_HIP_SPMV_PIPE && requested == LANCZOS_HIP_SPMV_AUTO && uneven)
         spmv_kind = LANCZOS_HIP_SPMV_MERGE;
     if (spmv_kind == LANCZOS_HIP_SPMV_MERGE) {
         const int64_t tiles = (nnz + kTile - 1) / kTile;
@@ -377,7 +390,7 @@ int Engine::choose_spmv(int requested) {
     else if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
         snprintf(spmv_name, sizeof(spmv_name), "dict%d", dict_patterns);
     else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
-        snprintf(spmv_name, sizeof(spmv_name), "panel%d", panel_bits);
+        snprintf(spmv_name, sizeof(spmv_name), "panel%d%s", panel_bits, rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
         snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)

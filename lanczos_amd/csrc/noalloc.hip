@@ -1,8 +1,9 @@
 // lanczos_hip_spmv_noalloc: the SpMV of an engine on device vectors, without any allocation.
 //
 // lanczos_hip_spmv stages its host vectors through two hipMalloc'd buffers per call and the SpMV
-// kernels leave their partial sums (and, in the merge form, the rows shared between tiles) in
-// buffers the engine allocated.  Callers that must not allocate -- a stream under HIP graph
+// kernels leave their partial sums (and, in the merge form, the rows shared between tiles; in the
+// tiled form, the sums of the pieces of row blocks too full for one workgroup) in buffers the
+// engine allocated.  Callers that must not allocate -- a stream under HIP graph
 // capture, a serving loop, a harness that forbids hipMalloc -- get the same kernels here with that
 // scratch memory in a fixed array that lives in the library's device image: kScratchBytes per GPU
 // the library runs on, held until the process ends.
@@ -75,6 +76,10 @@ int Engine::spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev) {
         return fail("lanczos_hip_spmv_noalloc: the matrix has %lld entries; on the merge SpMV this entry point takes "
                     "at most %lld (fixed scratch of %zu bytes)",
                     (long long)nnz, (long long)(kMaxMergeTiles * kMergeTile), kScratchBytes);
+    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL && (int64_t)tile_nslots * 4096 > 2 * kMaxMergeTiles)
+        return fail("lanczos_hip_spmv_noalloc: the tiled SpMV of this matrix cuts its fullest row blocks into %d pieces; "
+                    "this entry point takes at most %lld (fixed scratch of %zu bytes)",
+                    tile_nslots, (long long)(2 * kMaxMergeTiles / 4096), kScratchBytes);
     Scratch *s = nullptr;
     if (int rc = scratch_for_device(device, &s)) return rc;
     // The kernels take their scratch as arguments; hand them the fixed array for this one launch.
@@ -88,12 +93,15 @@ int Engine::spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev) {
         d_carry_val = s->carry_val;
         d_carry_row = s->carry_row;
     }
+    double *const keep_side = d_tside;
+    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL && tile_nslots > 0) d_tside = s->carry_val;
     profile = false;  // the event pool may have to create events
     int nparts = 0;
     int rc = launch_spmv(x_dev, x_dev, y_dev, &nparts);
     d_partials = keep_parts;
     d_carry_val = keep_cval;
     d_carry_row = keep_crow;
+    d_tside = keep_side;
     profile = keep_profile;
     if (rc) return rc;
     if (dot_dev) {

@@ -1,17 +1,22 @@
 // SpMV by tiles, for matrices whose rows reach all over a vector that is too
-// large for the caches (random sparsity: the row-wise product of
-// src/crs.c:155-178 then fetches one memory line per entry, and the fabric's
+// large for the caches (random sparsity, power-law graphs: the row-wise product
+// of src/crs.c:155-178 then fetches one memory line per entry, and the fabric's
 // request rate, not its bandwidth, sets the time).  The entries are regrouped
 // once, on the device, by (row block, column panel): a row block is 4096 rows,
 // whose part of y a workgroup keeps in LDS; a panel is 2^bits columns, whose
-// slice of x fits an XCD's L2.  A workgroup owns one row block and sweeps the
-// panels in order; the workgroups of a launch start together and carry equal
-// work per panel, so they sweep in step and the gathers hit L2.  Each entry is
-// 12 bytes as in CRS (value + row-in-block and column-in-panel packed into 32
-// bits).  Inside a tile the entries are sorted by row; a 256-entry chunk is
-// multiplied lane per entry, and the first lane of every run of equal rows adds
-// the run to the row's LDS slot, chunks separated by barriers: no atomics, the
-// same sums on every run.
+// slice of x fits an XCD's L2.  A block's entries form one stream, panel after
+// panel, cut into chunks of 256; inside a chunk the entries are sorted by row
+// (stable, so a row's entries keep their panel order).  A workgroup takes a
+// piece of at most 1024 chunks of one block: a chunk is multiplied lane per
+// entry, runs of equal rows are summed inside each wavefront (a segmented
+// shuffle scan) and the first lane of a run adds it to the row's LDS slot,
+// collecting the parts of a run that crosses wavefronts; chunks are separated
+// by barriers -- no atomics, the same sums on every run.  A block that fits one piece goes straight to y; the pieces of a
+// larger block (the hub rows of a power-law graph put 2 % of all entries into
+// one block) leave their 4096 sums in a side buffer, and a second kernel adds
+// them in piece order.  Workgroups of one launch start together; where the
+// blocks carry equal work they sweep the panels in step and the gathers hit
+// L2.  14 bytes per entry: value, column, row in block.
 #include <hipcub/hipcub.hpp>
 
 #include <stdlib.h>
@@ -27,8 +32,13 @@ namespace lz {
 static constexpr int kBlock = 256;
 static constexpr int kRowBits = 12;             // rows per block = 4096 (32 KiB of y in LDS)
 static constexpr int kRowsPerBlock = 1 << kRowBits;
-static constexpr int kColField = 20;            // bits of the packed word that hold the column in its panel
-static constexpr int kBlocksPerLaunch = 1024;   // 4 workgroups per CU: all of a launch are resident together
+static constexpr int kPieceChunks = 512;        // chunks of 256 entries in one piece at most (131 072 entries)
+static constexpr int kGroups = 1024;            // 4 workgroups per CU, all resident together; they draw pieces in order
+static constexpr int kCombineGroups = 256;      // workgroups that add up the pieces of split blocks
+
+// slot < 0: the piece is its whole block and writes y; else it writes sums to side-buffer slot `slot`
+struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; };
+struct TileSplit { int32_t block; int32_t slot0; int32_t count; int32_t unused; };
 
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
@@ -43,104 +53,204 @@ k_tile_keys(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
         }
 }
 
-// position q of the tile order holds entry idx[q]
+// block_ptr[K] = first position of the sorted keys that belongs to row block K or a later one, K = 0..nblocks
 __global__ void __launch_bounds__(kBlock)
-k_tile_place(int64_t nnz, const uint32_t *__restrict__ idx, const int32_t *__restrict__ rowid,
-             const int32_t *__restrict__ col, const double *__restrict__ val, int bits,
-             uint32_t *__restrict__ packed, double *__restrict__ pval) {
+k_block_bounds(int64_t nnz, const uint32_t *__restrict__ keys, int64_t nblocks, int jbits,
+               uint32_t *__restrict__ block_ptr) {
     const int64_t step = (int64_t)gridDim.x * kBlock;
-    const uint32_t cmask = (1u << bits) - 1u;
-    for (int64_t q = (int64_t)blockIdx.x * kBlock + threadIdx.x; q < nnz; q += step) {
-        const uint32_t e = idx[q];
-        packed[q] = ((uint32_t)(rowid[e] & (kRowsPerBlock - 1)) << kColField) | ((uint32_t)col[e] & cmask);
-        pval[q] = val[e];
-    }
-}
-
-// tile_ptr[t] = first position whose key is >= key(t), t = K * panels + J, for t = 0..tiles
-__global__ void __launch_bounds__(kBlock)
-k_tile_bounds(int64_t nnz, const uint32_t *__restrict__ keys, int64_t tiles, int panels, int jbits,
-              uint32_t *__restrict__ tile_ptr) {
-    const int64_t step = (int64_t)gridDim.x * kBlock;
-    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t <= tiles; t += step) {
-        const uint64_t want = ((uint64_t)(t / panels) << jbits) | (uint64_t)(t % panels);
+    for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t <= nblocks; t += step) {
+        const uint64_t want = (uint64_t)t << jbits;
         int64_t lo = 0, hi = nnz;
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
             if ((uint64_t)keys[mid] < want) lo = mid + 1;
             else hi = mid;
         }
-        tile_ptr[t] = (uint32_t)lo;
+        block_ptr[t] = (uint32_t)lo;
     }
 }
 
-// One workgroup = one block of 4096 rows: y block in LDS, panels swept in order.  partials[b]
-// receives (first launch) or accumulates (later launches, stream ordered) xdot . y of the block.
+// One workgroup per chunk: the chunk's entries (positions of the (block, panel) order) sorted by
+// row in block, stable, and written out as the stream the product reads.  chunk_first[K] = number
+// of chunks of the blocks before K.
 __global__ void __launch_bounds__(kBlock)
-k_spmv_tiles(int64_t n, int64_t block0, int64_t nblocks, int panels, int bits,
-             const uint32_t *__restrict__ tile_ptr, const uint32_t *__restrict__ packed,
-             const double *__restrict__ pval, const double *__restrict__ x, const double *__restrict__ xdot,
-             double *__restrict__ y, double *__restrict__ partials, int accumulate) {
+k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chunk_first,
+             const uint32_t *__restrict__ block_ptr, const uint32_t *__restrict__ idx,
+             const int32_t *__restrict__ rowid, const int32_t *__restrict__ col, const double *__restrict__ val,
+             uint16_t *__restrict__ trow, uint32_t *__restrict__ tcol, double *__restrict__ tval) {
+    using Sort = hipcub::BlockRadixSort<uint32_t, kBlock, 1, uint32_t>;
+    __shared__ typename Sort::TempStorage tmp;
+    for (uint32_t g = blockIdx.x; g < chunks; g += gridDim.x) {
+        int64_t lo = 0, hi = nblocks;              // the last K with chunk_first[K] <= g
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (chunk_first[mid] <= g) lo = mid;
+            else hi = mid;
+        }
+        const uint32_t q = block_ptr[lo] + (g - chunk_first[lo]) * (uint32_t)kBlock + threadIdx.x;
+        uint32_t key[1] = {(uint32_t)kRowsPerBlock}, e[1] = {0};
+        if (q < block_ptr[lo + 1]) {
+            e[0] = idx[q];
+            key[0] = (uint32_t)rowid[e[0]] & (uint32_t)(kRowsPerBlock - 1);
+        }
+        Sort(tmp).Sort(key, e, 0, kRowBits + 1);
+        if (key[0] < (uint32_t)kRowsPerBlock) {   // the empty lanes of a block's last chunk sort to its end
+            trow[q] = (uint16_t)key[0];
+            tcol[q] = (uint32_t)col[e[0]];
+            tval[q] = val[e[0]];
+        }
+        __syncthreads();
+    }
+}
+
+// A workgroup takes piece piece0 + its own number and then, with draw set, draws further ones from
+// a counter (zero at launch) until none is left.  A piece that is a whole block writes
+// its rows of y and dots[piece] = xdot . y over them; a share of a block writes its sums to the side
+// buffer and dots[piece] = 0.
+__global__ void __launch_bounds__(kBlock)
+k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__restrict__ pieces,
+             const uint32_t *__restrict__ block_ptr, const uint16_t *__restrict__ trow,
+             const uint32_t *__restrict__ tcol, const double *__restrict__ tval, const double *__restrict__ x,
+             const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ side,
+             double *__restrict__ dots, int *__restrict__ counter) {
     __shared__ double ylds[kRowsPerBlock];
-    __shared__ double sp[kBlock];
-    __shared__ int sr[kBlock];
+    __shared__ double wsum[kBlock / 64];     // per wavefront: sum of the run that starts at its lane 0,
+    __shared__ int wrow[kBlock / 64];        //   that run's row,
+    __shared__ int wfull[kBlock / 64];       //   whether the run fills the wavefront,
+    __shared__ int wlast[kBlock / 64];       //   and the row of its lane 63
     __shared__ double red[kBlock / 64];
-    const int tid = threadIdx.x;
-    const int64_t K = block0 + blockIdx.x;
-    double acc = 0.0;
-    if (K < nblocks) {
+    __shared__ int next;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    // the first piece is the workgroup's own number, the later ones are drawn; pi is kept in a scalar
+    // register (readfirstlane) so that the loop, with its barriers, stays uniform for the compiler too
+    int pi = piece0 + (int)blockIdx.x;
+    while (pi < npieces) {
+        double acc = 0.0;
+        const TilePiece pc = pieces[pi];
         for (int i = tid; i < kRowsPerBlock; i += kBlock) ylds[i] = 0.0;
         __syncthreads();
-        const uint32_t *tp = tile_ptr + K * panels;
-        for (int J = 0; J < panels; ++J) {
-            const uint32_t a = tp[J], b = tp[J + 1];
-            const double *xp = x + ((int64_t)J << bits);
-            for (uint32_t q0 = a; q0 < b; q0 += kBlock) {
-                const uint32_t q = q0 + tid;
-                int r = -1;
-                double prod = 0.0;
-                if (q < b) {
-                    const uint32_t pk = __builtin_nontemporal_load(packed + q);
-                    prod = __builtin_nontemporal_load(pval + q) * xp[pk & ((1u << kColField) - 1u)];
-                    r = (int)(pk >> kColField);
-                }
-                sp[tid] = prod;
-                sr[tid] = r;
-                __syncthreads();
-                if (r >= 0 && (tid == 0 || sr[tid - 1] != r)) {
-                    double sum = prod;
-                    for (int j = tid + 1; j < kBlock && sr[j] == r; ++j) sum += sp[j];
-                    ylds[r] += sum;
-                }
-                __syncthreads();
+        const uint32_t a = block_ptr[pc.block] + pc.chunk0 * (uint32_t)kBlock;
+        const uint64_t stop = (uint64_t)a + (uint64_t)pc.chunks * kBlock;
+        const uint32_t b = stop < (uint64_t)block_ptr[pc.block + 1] ? (uint32_t)stop : block_ptr[pc.block + 1];
+        for (uint32_t q0 = a; q0 < b; q0 += kBlock) {
+            const uint32_t q = q0 + tid;
+            int r = -1;
+            double sum = 0.0;
+            if (q < b) {
+                const uint32_t c = __builtin_nontemporal_load(tcol + q);
+                r = (int)__builtin_nontemporal_load(trow + q);
+                sum = __builtin_nontemporal_load(tval + q) * x[c];
             }
+            // runs of equal rows inside the wavefront: after the scan a run's first lane holds its sum
+            const int rprev = __shfl_up(r, 1);
+            const bool head = lane == 0 || rprev != r;
+            const unsigned long long heads = __ballot(head);
+            const unsigned long long above = lane == 63 ? 0ull : (heads >> (lane + 1)) << (lane + 1);
+            const int end = above ? __ffsll((long long)above) - 1 : 64;      // first lane of the next run
+            // offset s is needed only when some run is longer than s, i.e. s lanes in a row continue a run
+            unsigned long long cont = ~heads;
+#pragma unroll
+            for (int s = 1; s < 64 && cont; s <<= 1) {
+                const double t = __shfl_down(sum, s);
+                if (lane + s < end) sum += t;
+                cont &= cont >> s;
+            }
+            if (lane == 0) {
+                wsum[w] = sum;
+                wrow[w] = r;
+                wfull[w] = end == 64;
+            }
+            if (lane == 63) wlast[w] = r;
+            __syncthreads();
+            // a run that crosses wavefronts is added by its first part, which collects the others in order
+            if (head && r >= 0 && !(lane == 0 && w > 0 && wlast[w - 1] == r)) {
+                if (end == 64)
+                    for (int v = w + 1; v < kBlock / 64 && wrow[v] == r; ++v) {
+                        sum += wsum[v];
+                        if (!wfull[v]) break;
+                    }
+                ylds[r] += sum;
+            }
+            __syncthreads();
         }
-        const int64_t row0 = K << kRowBits;
+        if (pc.slot < 0) {
+            const int64_t row0 = (int64_t)pc.block << kRowBits;
+            for (int i = tid; i < kRowsPerBlock; i += kBlock)
+                if (row0 + i < n) {
+                    const double v = ylds[i];
+                    y[row0 + i] = v;
+                    acc += xdot[row0 + i] * v;
+                }
+        } else {
+            double *out = side + (int64_t)pc.slot * kRowsPerBlock;
+            for (int i = tid; i < kRowsPerBlock; i += kBlock) out[i] = ylds[i];
+        }
+        // workgroup sum in a fixed order
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+        if (lane == 0) red[w] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            dots[pi] = (red[0] + red[1]) + (red[2] + red[3]);
+            next = draw ? (int)gridDim.x + atomicAdd(counter, 1) : npieces;
+        }
+        __syncthreads();
+        pi = __builtin_amdgcn_readfirstlane(next);
+    }
+}
+
+// y of the split blocks: their pieces' sums added in piece order; dots[workgroup] = its xdot . y
+__global__ void __launch_bounds__(kBlock)
+k_tiles_combine(int64_t n, int nsplit, const TileSplit *__restrict__ splits, const double *__restrict__ side,
+                const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ dots) {
+    __shared__ double red[kBlock / 64];
+    const int tid = threadIdx.x;
+    double acc = 0.0;
+    for (int m = blockIdx.x; m < nsplit; m += gridDim.x) {
+        const TileSplit sp = splits[m];
+        const int64_t row0 = (int64_t)sp.block << kRowBits;
         for (int i = tid; i < kRowsPerBlock; i += kBlock)
             if (row0 + i < n) {
-                const double v = ylds[i];
+                double v = 0.0;
+                for (int p = 0; p < sp.count; ++p) v += side[(int64_t)(sp.slot0 + p) * kRowsPerBlock + i];
                 y[row0 + i] = v;
                 acc += xdot[row0 + i] * v;
             }
     }
-    // workgroup sum in a fixed order
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
     __syncthreads();
-    if (tid == 0) {
-        const double t = (red[0] + red[1]) + (red[2] + red[3]);
-        partials[blockIdx.x] = accumulate ? partials[blockIdx.x] + t : t;
-    }
+    if (tid == 0) dots[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// partials[t] = sum of dots[t], dots[t + 256], ... : the per-piece dots folded to 256 partial sums
+__global__ void __launch_bounds__(kBlock)
+k_tiles_fold(int count, const double *__restrict__ dots, double *__restrict__ partials) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += kBlock) s += dots[i];
+    partials[threadIdx.x] = s;
 }
 
 void Engine::free_panels() {
-    (void)hipFree(d_packed);
+    (void)hipFree(d_trow);
+    (void)hipFree(d_tcol);
     (void)hipFree(d_pval);
-    (void)hipFree(d_tile_ptr);
-    d_packed = nullptr;
+    (void)hipFree(d_tblock_ptr);
+    (void)hipFree(d_tpieces);
+    (void)hipFree(d_tsplits);
+    (void)hipFree(d_tside);
+    (void)hipFree(d_tdots);
+    (void)hipFree(d_tcounter);
+    d_tdots = nullptr;
+    d_tcounter = nullptr;
+    d_trow = nullptr;
+    d_tcol = nullptr;
     d_pval = nullptr;
-    d_tile_ptr = nullptr;
+    d_tblock_ptr = nullptr;
+    d_tpieces = nullptr;
+    d_tsplits = nullptr;
+    d_tside = nullptr;
     tile_panels = 0;
+    tile_npieces = tile_nsplit = tile_nslots = 0;
 }
 
 // Regroup the device CRS by (row block, column panel).  tile_panels > 0 afterwards when the form
@@ -148,16 +258,15 @@ void Engine::free_panels() {
 // wider than 32 bits).  Non-zero return on errors.
 int Engine::build_panels(int bits) {
     free_panels();
-    if (bits > kColField) bits = kColField;
-    if (nnz == 0 || nnz >= ((int64_t)1 << 32)) return 0;
+    if (bits > 24) bits = 24;
+    if (nnz == 0 || nnz >= ((int64_t)1 << 32) - kBlock) return 0;
     const int panels = (int)(((n_ext - 1) >> bits) + 1);
     const int64_t nblocks = (n + kRowsPerBlock - 1) >> kRowBits;
     int jbits = 1, kbits = 1;
     while ((1 << jbits) < panels) jbits++;
     while (((int64_t)1 << kbits) < nblocks) kbits++;
     if (jbits + kbits > 32) return 0;
-    const int64_t tiles = nblocks * panels;
-    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr};
+    uint32_t *d_keys[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr}, *d_chunk_first = nullptr;
     int32_t *d_rowid = nullptr;
     void *d_tmp = nullptr;
     auto cleanup = [&]() {
@@ -167,6 +276,7 @@ int Engine::build_panels(int bits) {
         (void)hipFree(d_idx[1]);
         (void)hipFree(d_rowid);
         (void)hipFree(d_tmp);
+        (void)hipFree(d_chunk_first);
     };
 #define PN_TRY(call)                                                                                   \
     do {                                                                                               \
@@ -199,32 +309,109 @@ int Engine::build_panels(int bits) {
     PN_TRY(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
     PN_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, keys, vals, (unsigned int)nnz, 0, jbits + kbits,
                                               stream));
-    PN_TRY(hipMalloc(&d_packed, sizeof(uint32_t) * nnz));
-    PN_TRY(hipMalloc(&d_pval, sizeof(double) * nnz));
-    PN_TRY(hipMalloc(&d_tile_ptr, sizeof(uint32_t) * (tiles + 1)));
-    const int eblocks = (int)std::min<int64_t>(max_blocks, (nnz + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_tile_place, dim3(eblocks), dim3(kBlock), 0, stream, nnz, (const uint32_t *)vals.Current(),
-                       (const int32_t *)d_rowid, (const int32_t *)d_col, (const double *)d_val, bits, d_packed, d_pval);
-    const int tblocks = (int)std::min<int64_t>(max_blocks, (tiles + 1 + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL(k_tile_bounds, dim3(tblocks), dim3(kBlock), 0, stream, nnz, (const uint32_t *)keys.Current(),
-                       tiles, panels, jbits, d_tile_ptr);
+    PN_TRY(hipMalloc(&d_tblock_ptr, sizeof(uint32_t) * (nblocks + 1)));
+    const int bblocks = (int)std::min<int64_t>(max_blocks, (nblocks + 1 + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL(k_block_bounds, dim3(bblocks), dim3(kBlock), 0, stream, nnz, (const uint32_t *)keys.Current(),
+                       nblocks, jbits, d_tblock_ptr);
     PN_TRY(hipGetLastError());
+    // the pieces: whole blocks where they fit, shares of at most kPieceChunks chunks otherwise
+    std::vector<uint32_t> bp, cf;
+    std::vector<TilePiece> pieces;
+    std::vector<TileSplit> splits;
+    int slots = 0;
+    try {
+        bp.resize(nblocks + 1);
+        cf.resize(nblocks + 1);
+        PN_TRY(hipMemcpyAsync(bp.data(), d_tblock_ptr, sizeof(uint32_t) * (nblocks + 1), hipMemcpyDeviceToHost, stream));
+        PN_TRY(hipStreamSynchronize(stream));
+        uint64_t chunks = 0;
+        uint32_t most = 0;
+        for (int64_t K = 0; K < nblocks; ++K) {
+            cf[K] = (uint32_t)chunks;
+            const uint32_t c = (bp[K + 1] - bp[K] + kBlock - 1) / kBlock;
+            chunks += c;
+            most = std::max(most, c);
+        }
+        // Blocks of about equal weight, and enough of them to go round, stay whole.  Otherwise a piece holds
+        // at most `limit` chunks: half of a workgroup's share of the matrix, within [64, kPieceChunks], so
+        // that no piece is a long pole.
+        tile_even = nblocks >= kGroups / 4 && 4 * (uint64_t)most <= 5 * (chunks / (uint64_t)nblocks) + 8;
+        const uint32_t limit =
+            tile_even ? most : (uint32_t)std::min<uint64_t>(kPieceChunks, std::max<uint64_t>(64, chunks / (2 * kGroups)));
+        for (int64_t K = 0; K < nblocks; ++K) {
+            const uint32_t c = (bp[K + 1] - bp[K] + kBlock - 1) / kBlock;
+            if (c <= limit) {
+                pieces.push_back({(int32_t)K, 0u, (int32_t)c, -1});     // empty blocks too: their rows of y are zeros
+            } else {
+                splits.push_back({(int32_t)K, slots, 0, 0});
+                for (uint32_t c0 = 0; c0 < c; c0 += limit, ++slots, ++splits.back().count)
+                    pieces.push_back({(int32_t)K, c0, (int32_t)std::min<uint32_t>(limit, c - c0), slots});
+            }
+        }
+        cf[nblocks] = (uint32_t)chunks;
+    } catch (const std::bad_alloc &) {
+        cleanup();
+        free_panels();
+        return fail("lanczos_hip_create: out of host memory while planning the tiled SpMV");
+    }
+    const uint32_t chunks = cf[nblocks];
+    PN_TRY(hipMalloc(&d_chunk_first, sizeof(uint32_t) * (nblocks + 1)));
+    PN_TRY(hipMemcpyAsync(d_chunk_first, cf.data(), sizeof(uint32_t) * (nblocks + 1), hipMemcpyHostToDevice, stream));
+    PN_TRY(hipMalloc(&d_trow, sizeof(uint16_t) * nnz));
+    PN_TRY(hipMalloc(&d_tcol, sizeof(uint32_t) * nnz));
+    PN_TRY(hipMalloc(&d_pval, sizeof(double) * nnz));
+    if (chunks > 0)
+        hipLaunchKernelGGL(k_tile_place, dim3((unsigned)std::min<uint32_t>(chunks, 65536u * 16u)), dim3(kBlock), 0, stream,
+                           chunks, nblocks, (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
+                           (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
+                           (const double *)d_val, d_trow, d_tcol, d_pval);
+    PN_TRY(hipGetLastError());
+    PN_TRY(hipMalloc(&d_tpieces, sizeof(TilePiece) * std::max<size_t>(pieces.size(), 1)));
+    PN_TRY(hipMemcpyAsync(d_tpieces, pieces.data(), sizeof(TilePiece) * pieces.size(), hipMemcpyHostToDevice, stream));
+    if (!splits.empty()) {
+        PN_TRY(hipMalloc(&d_tsplits, sizeof(TileSplit) * splits.size()));
+        PN_TRY(hipMemcpyAsync(d_tsplits, splits.data(), sizeof(TileSplit) * splits.size(), hipMemcpyHostToDevice, stream));
+        PN_TRY(hipMalloc(&d_tside, sizeof(double) * (size_t)slots * kRowsPerBlock));
+    }
+    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + kCombineGroups)));
+    PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
     PN_TRY(hipStreamSynchronize(stream));
     cleanup();
 #undef PN_TRY
     tile_panels = panels;
     tile_bits = bits;
-    tile_blocks_n = nblocks;
+    tile_npieces = (int)pieces.size();
+    tile_nsplit = (int)splits.size();
+    tile_nslots = slots;
     return 0;
 }
 
 int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts) {
-    int launches = 0;
-    for (int64_t b0 = 0; b0 < tile_blocks_n; b0 += kBlocksPerLaunch, ++launches)
-        hipLaunchKernelGGL(k_spmv_tiles, dim3(kBlocksPerLaunch), dim3(kBlock), 0, stream, n, b0, tile_blocks_n,
-                           tile_panels, tile_bits, (const uint32_t *)d_tile_ptr, (const uint32_t *)d_packed,
-                           (const double *)d_pval, x, xdot, y, d_partials, launches > 0 ? 1 : 0);
-    *nparts = kBlocksPerLaunch;
+    if (tile_even) {
+        // equal work in every piece: launches of kGroups workgroups that start together and sweep the
+        // panels in step, so that an XCD's L2 holds one panel's slice of x at a time
+        for (int p0 = 0; p0 < tile_npieces; p0 += kGroups)
+            hipLaunchKernelGGL(k_spmv_tiles, dim3(std::min(kGroups, tile_npieces - p0)), dim3(kBlock), 0, stream, n, p0,
+                               tile_npieces, 0, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr,
+                               (const uint16_t *)d_trow, (const uint32_t *)d_tcol, (const double *)d_pval, x, xdot, y,
+                               d_tside, d_tdots, d_tcounter);
+    } else {
+        // uneven pieces, fullest blocks first: one launch whose workgroups draw pieces as they finish
+        if (hipMemsetAsync(d_tcounter, 0, sizeof(int), stream) != hipSuccess)
+            return fail("lanczos_hip: clearing the tiled SpMV's piece counter failed");
+        hipLaunchKernelGGL(k_spmv_tiles, dim3(std::min(kGroups, tile_npieces)), dim3(kBlock), 0, stream, n, 0,
+                           tile_npieces, 1, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr,
+                           (const uint16_t *)d_trow, (const uint32_t *)d_tcol, (const double *)d_pval, x, xdot, y, d_tside,
+                           d_tdots, d_tcounter);
+    }
+    int count = tile_npieces;
+    if (tile_nsplit > 0) {
+        hipLaunchKernelGGL(k_tiles_combine, dim3(kCombineGroups), dim3(kBlock), 0, stream, n, tile_nsplit,
+                           (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces);
+        count += kCombineGroups;
+    }
+    hipLaunchKernelGGL(k_tiles_fold, dim3(1), dim3(kBlock), 0, stream, count, (const double *)d_tdots, d_partials);
+    *nparts = kBlock;
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;

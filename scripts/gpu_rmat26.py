@@ -6,8 +6,10 @@ reference (src/crs.h:4-21), and handed to the engine like any other matrix.  tor
 most 2^31-1 keys, so the (row, column) keys are sorted and merged per row range.
 
 Checks that need no second implementation: L * ones == 0 exactly, symmetry u.(Lv) == v.(Lu), sampled
-rows against direct evaluation.  Then timings of the single-vector path and of the block variant."""
+rows against direct evaluation.  Then timings of the single-vector path (SpMV form from RMAT_SPMV, default auto) and of the
+block variant (second argument: block steps, 0 skips it)."""
 import json
+import os
 import sys
 import time
 
@@ -45,7 +47,7 @@ out = {"scale": scale, "n": n, "nnz": nnz, "max_row": max_row, "rows_over_512": 
        "isolated_vertices": isolated, "generate_s": time.perf_counter() - T0}
 rng = np.random.default_rng(1)
 t0 = time.perf_counter()
-with la.Engine(a, 33, reorth="none", profile=True) as e:
+with la.Engine(a, 33, reorth="none", spmv=os.environ.get("RMAT_SPMV", "auto"), profile=True) as e:
     out["engine_create_s"] = time.perf_counter() - t0
     out["spmv_kernel"] = e.spmv_name
     log(f"engine up in {out['engine_create_s']:.1f}s, kernel {e.spmv_name}")
@@ -76,6 +78,9 @@ with la.Engine(a, 33, reorth="none", profile=True) as e:
     log(f"single vector: {out['single_none']}")
 del au, av, u, v, y
 
+if block_steps == 0:
+    print(json.dumps(out, indent=1))
+    sys.exit(0)
 with la.BlockEngine(a, block_steps, profile=True) as e:
     e.set_start_seed(1)
     e.run(1)

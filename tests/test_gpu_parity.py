@@ -255,6 +255,42 @@ def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
         assert e.spmv_name == "dict27"
 
 
+def test_panel_spmv_on_power_law_graph(gpu, monkeypatch):
+    """The tiled form on hub rows: the fullest row blocks are cut into pieces whose sums a second kernel
+    adds in order; same products as the row-wise oracle (src/crs.c:155-178), same Lanczos sequences,
+    bit for bit the same on every run."""
+    a = crs_from_scipy(rmat_laplacian(16))
+    x = np.random.default_rng(3).standard_normal(a.dimension)
+    want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+    v0 = la.gaussian_fill(4, 0, a.dimension)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 31, 0.0)
+    for bits in ("10", "12", "16"):
+        monkeypatch.setenv("LANCZOS_HIP_PANEL_BITS", bits)
+        with la.Engine(a, 31, spmv="panel") as e:
+            assert e.spmv_name == "panel" + bits
+            y = e.spmv(x)
+            assert np.all(np.abs(y - want) <= spmv_tolerance(a, x))
+            assert e.spmv(x).tobytes() == y.tobytes()
+            assert not e.spmv(np.ones(a.dimension)).any()          # L * ones vanishes exactly
+            e.set_start(v0)
+            alpha, beta = e.run(30)
+            e.set_start(v0)
+            alpha2, beta2 = e.run(30)
+        assert alpha.tobytes() == alpha2.tobytes() and beta.tobytes() == beta2.tobytes()
+        assert rel_err(alpha, o.alpha) < 1e-11 and rel_err(beta, o.beta) < 1e-11
+    monkeypatch.delenv("LANCZOS_HIP_PANEL_BITS")
+    # one row block, far more entries than one workgroup takes: cut into pieces all the same
+    n = 3000
+    rng = np.random.default_rng(8)
+    head = np.arange(n + 1, dtype=np.int64) * 200
+    dense = la.CrsMatrix(rng.standard_normal(n * 200), rng.integers(0, n, n * 200).astype(np.int64), head)
+    xd = rng.standard_normal(n)
+    with la.Engine(dense, 3, spmv="panel") as e:
+        yd = e.spmv(xd)
+    assert np.all(np.abs(yd - oracle.matvec_crs(dense.row_head_indexes, dense.column_index, dense.values, xd))
+                  <= spmv_tolerance(dense, xd))
+
+
 def test_device_coo_to_crs_is_bit_exact(gpu, golden_dir):
     """Device build against the reference's own crs.c output and against the host build."""
     from test_oracle_golden import CASES, read_ref_bin

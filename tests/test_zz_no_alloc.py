@@ -40,6 +40,9 @@ def test_noalloc_two_calls_second_smaller(gpu):
     # merge form (the carry lists live in the scratch array): a larger graph, then a smaller one
     assert check(crs_from_scipy(rmat_laplacian(15)), "merge", 1).startswith("merge")
     assert check(crs_from_scipy(rmat_laplacian(12)), "merge", 2).startswith("merge")
+    # tiled form on the same kind of graph (the sums of the pieces of split row blocks live there too)
+    assert check(crs_from_scipy(rmat_laplacian(13)), "panel", 7).startswith("panel")
+    assert check(crs_from_scipy(rmat_laplacian(12)), "panel", 8).startswith("panel")
     # automatic choice on stencils (dictionary form), again large then small
     assert check(la.synth_laplacian(3, 40), "auto", 3).startswith("dict")
     assert check(la.synth_laplacian(3, 11), "auto", 4).startswith("dict")
@@ -65,3 +68,10 @@ def test_noalloc_rejects_what_the_scratch_cannot_hold(gpu):
             e.spmv_noalloc(xd.data_ptr(), yd.data_ptr(), None)
         with pytest.raises(la.LanczosHipError, match="NULL"):
             e.spmv_noalloc(None, yd.data_ptr(), None)
+    # tiled form: at most 64 pieces of split row blocks fit the scratch
+    g = crs_from_scipy(rmat_laplacian(16))
+    with la.Engine(g, 3, spmv="panel") as e:
+        xd = torch.ones(g.dimension, dtype=torch.float64, device="cuda")
+        yd = torch.zeros(g.dimension, dtype=torch.float64, device="cuda")
+        with pytest.raises(la.LanczosHipError, match="takes at most 64"):
+            e.spmv_noalloc(xd.data_ptr(), yd.data_ptr(), None)
