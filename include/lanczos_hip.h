@@ -101,7 +101,8 @@ typedef struct crs {
  *   LANCZOS_HIP_NO_DICT    1 keeps the CRS kernels on matrices whose rows repeat
  *   LANCZOS_HIP_PIN_UPLOAD 0 uploads from pageable memory (default: the caller's arrays are page-locked
  *                          around the copies, as src/lanczos_cuda.c:144, 168 do)
- *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 18)
+ *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 16; 12 on matrices
+ *                          with wildly uneven rows)
  */
 int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
                     int nth_eig, int max_iter, double threshold);
@@ -154,10 +155,12 @@ enum {
     LANCZOS_HIP_SPMV_ROWS = 5,   /* pipe form whose gathers run row-wise (coalesced for stencil-like
                                     matrices); needs every 64-row group to hold <= 481 entries */
     LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
-                                    caches (random sparsity): entries regrouped on the device by
-                                    (block of 4096 rows, column panel of 2^18 columns); a workgroup keeps
-                                    its rows of y in LDS and sweeps the panels, whose slice of x stays in
-                                    L2.  LANCZOS_HIP_PANEL_BITS overrides the panel width. */
+                                    caches (random sparsity, large power-law graphs): entries regrouped on
+                                    the device by (block of 4096 rows, column panel of 2^16 or 2^12 columns);
+                                    a workgroup keeps its rows of y in LDS and sweeps the panels, whose slice
+                                    of x stays in cache; row blocks too full for one workgroup are cut into
+                                    pieces whose sums a second kernel adds in order.  Needs nnz < 2^32.
+                                    LANCZOS_HIP_PANEL_BITS overrides the panel width. */
     LANCZOS_HIP_SPMV_DICT = 7,   /* dictionary of row patterns ((col - row, value) lists): one 16-bit pattern
                                     number per row replaces the row's entries; for matrices whose rows
                                     repeat (stencils on grids), at most 65535 patterns of at most 32
@@ -293,10 +296,11 @@ int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host
  * allocate: a stream under HIP graph capture, a tight serving loop, a harness that forbids
  * hipMalloc -- lanczos_hip_spmv stages its host vectors through two hipMalloc'd buffers per call.
  * The kernels are the ones lanczos_hip_spmv runs (y is bit for bit the same); their scratch memory
- * (per-workgroup partial sums and, on the merge SpMV, the rows shared between tiles) is a fixed
- * array of 3 178 496 bytes in the library's device image, one copy per GPU, held until the
- * process ends.  Limits: on the merge SpMV at most 67 108 864 entries, otherwise none beyond the
- * engine's own; beyond it the call fails with a message and launches nothing.  Calls on the same
+ * (per-workgroup partial sums; on the merge SpMV the rows shared between tiles; on the tiled SpMV
+ * the sums of the pieces of split row blocks) is a fixed array of 3 178 496 bytes in the library's
+ * device image, one copy per GPU, held until the process ends.  Limits: on the merge SpMV at most
+ * 67 108 864 entries, on the tiled SpMV at most 64 pieces of split row blocks, otherwise none beyond
+ * the engine's own; beyond them the call fails with a message and launches nothing.  Calls on the same
  * GPU share the array: two that overlap in time (different streams or threads) race on it.
  */
 int lanczos_hip_spmv_noalloc(lanczos_hip_engine *e, const double *x_dev, double *y_dev, double *dot_dev);
@@ -313,12 +317,13 @@ int lanczos_hip_profile(const lanczos_hip_engine *e, int kernel_class, double *m
                         int64_t *launches, double *bytes);
 void lanczos_hip_profile_reset(lanczos_hip_engine *e);
 
-/* Name of the SpMV kernel variant the engine selected ("dict27", "rows64", "pipe16", "panel18",
+/* Name of the SpMV kernel variant the engine selected ("dict27", "rows64", "pipe16", "panel16",
  * "merge", "vector8", ...).  LANCZOS_HIP_SPMV_AUTO decides from the matrix as it sits on the device:
  * when, on a sample of rows, most neighbouring rows hold neighbouring columns, "dict" if the rows
  * repeat as at most 65535 patterns, else "rows" if every 64-row group fits one tile; otherwise
- * "panel" when the sampled rows reach across more than 16 MiB of the vector, "merge" when the
- * fullest 64-row group holds 16 times the average, else "pipe". */
+ * "panel" when the sampled rows reach across more than 16 MiB of the vector; when the fullest
+ * 64-row group holds 16 times the average, "panel" (narrow panels, split row blocks) if the vector
+ * exceeds 40 MiB and "merge" below that; else "pipe". */
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
 
 /*

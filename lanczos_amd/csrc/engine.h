@@ -92,15 +92,20 @@ struct Engine {
     double *d_carry_val = nullptr;
     long long *d_xcd_split = nullptr;  // [9] chunk ranges of the pipe kernel, equal entries per XCD
     // tiled form of the matrix (LANCZOS_HIP_SPMV_PANEL): entries grouped by (row block, column panel)
-    uint16_t *d_trow = nullptr;      // row in its 4096-row block
-    uint32_t *d_tcol = nullptr;      // column
+    uint16_t *d_trow = nullptr;      // row in its 4096-row block (unpacked form)
+    uint32_t *d_tcol = nullptr;      // column; packed form: row in block << 20 | column - d_tbase[chunk]
+    uint32_t *d_tbase = nullptr;     // packed form: smallest column of each chunk
+    uint32_t *d_tfar_entry = nullptr;  // packed form: CRS positions of the entries whose column is too far from
+    int32_t *d_tfar_row = nullptr;     //   their chunk's first (sorted), and their rows; added by a kernel of their own
+    int tile_nfar = 0;
+    bool tile_packed = false;
     double *d_pval = nullptr;
     uint32_t *d_tblock_ptr = nullptr;  // [row blocks + 1] first stream position of each block
     void *d_tpieces = nullptr, *d_tsplits = nullptr;  // work items; blocks cut into several of them
     double *d_tside = nullptr;       // [tile_nslots][4096] sums of the pieces of split blocks
     double *d_tdots = nullptr;       // [pieces + 256] xdot . y of each piece, of the combining workgroups
     int *d_tcounter = nullptr;       // next piece to draw
-    int tile_panels = 0, tile_bits = 18, panel_bits = 18;
+    int tile_panels = 0, tile_bits = 16, panel_bits = 16;
     int tile_npieces = 0, tile_nsplit = 0, tile_nslots = 0;
     bool tile_even = false;          // every piece carries about the same work
     // dictionary form of the matrix (LANCZOS_HIP_SPMV_DICT): one pattern number per row

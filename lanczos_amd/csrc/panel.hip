@@ -16,7 +16,9 @@
 // one block) leave their 4096 sums in a side buffer, and a second kernel adds
 // them in piece order.  Workgroups of one launch start together; where the
 // blocks carry equal work they sweep the panels in step and the gathers hit
-// L2.  14 bytes per entry: value, column, row in block.
+// L2.  12 bytes per entry (value; row in block and column relative to the
+// chunk's first in one word) where no chunk's columns span 2^20, else 14:
+// value, column, row in block.
 #include <hipcub/hipcub.hpp>
 
 #include <stdlib.h>
@@ -37,7 +39,10 @@ static constexpr int kGroups = 1024;            // 4 workgroups per CU, all resi
 static constexpr int kCombineGroups = 256;      // workgroups that add up the pieces of split blocks
 
 // slot < 0: the piece is its whole block and writes y; else it writes sums to side-buffer slot `slot`
-struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; };
+struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; uint32_t gchunk0; uint32_t unused; };
+static constexpr int kColField = 20;            // packed form: bits that hold the column relative to the chunk's first
+static constexpr uint32_t kFarColumn = (1u << kColField) - 1u;   // in the column field: no entry here (it is in the far list)
+static constexpr uint32_t kFarCap = 1u << 22;   // entries the far list holds at most
 struct TileSplit { int32_t block; int32_t slot0; int32_t count; int32_t unused; };
 
 template <typename RP>
@@ -72,14 +77,23 @@ k_block_bounds(int64_t nnz, const uint32_t *__restrict__ keys, int64_t nblocks, 
 
 // One workgroup per chunk: the chunk's entries (positions of the (block, panel) order) sorted by
 // row in block, stable, and written out as the stream the product reads.  chunk_first[K] = number
-// of chunks of the blocks before K.
+// of chunks of the blocks before K.  kPacked: one 32-bit word per entry, row in block << 20 | column -
+// base[chunk] with base the chunk's smallest column.  An entry 2^20 - 1 or more columns away from it
+// does not fit: its number goes to the far list (*far_count counts them, also beyond far_cap), and
+// its place in the stream, after the chunk's other entries, holds kFarColumn, which the product skips.
+template <bool kPacked>
 __global__ void __launch_bounds__(kBlock)
 k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chunk_first,
              const uint32_t *__restrict__ block_ptr, const uint32_t *__restrict__ idx,
              const int32_t *__restrict__ rowid, const int32_t *__restrict__ col, const double *__restrict__ val,
-             uint16_t *__restrict__ trow, uint32_t *__restrict__ tcol, double *__restrict__ tval) {
+             uint16_t *__restrict__ trow, uint32_t *__restrict__ tcol, double *__restrict__ tval,
+             uint32_t *__restrict__ base, int *__restrict__ far_count, uint32_t far_cap,
+             uint32_t *__restrict__ far_entry) {
     using Sort = hipcub::BlockRadixSort<uint32_t, kBlock, 1, uint32_t>;
+    using Reduce = hipcub::BlockReduce<uint32_t, kBlock>;
     __shared__ typename Sort::TempStorage tmp;
+    __shared__ typename Reduce::TempStorage rtmp;
+    __shared__ uint32_t lowest;
     for (uint32_t g = blockIdx.x; g < chunks; g += gridDim.x) {
         int64_t lo = 0, hi = nblocks;              // the last K with chunk_first[K] <= g
         while (hi - lo > 1) {
@@ -88,13 +102,38 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
             else hi = mid;
         }
         const uint32_t q = block_ptr[lo] + (g - chunk_first[lo]) * (uint32_t)kBlock + threadIdx.x;
-        uint32_t key[1] = {(uint32_t)kRowsPerBlock}, e[1] = {0};
-        if (q < block_ptr[lo + 1]) {
+        const bool inside = q < block_ptr[lo + 1];     // false in the empty lanes of a block's last chunk
+        uint32_t key[1] = {(uint32_t)kRowsPerBlock}, e[1] = {0xffffffffu};
+        uint32_t c = 0;
+        if (inside) {
             e[0] = idx[q];
             key[0] = (uint32_t)rowid[e[0]] & (uint32_t)(kRowsPerBlock - 1);
+            c = (uint32_t)col[e[0]];
+        }
+        if (kPacked) {
+            const uint32_t cmin = Reduce(rtmp).Reduce(inside ? c : 0xffffffffu, hipcub::Min());
+            if (threadIdx.x == 0) {
+                lowest = cmin;
+                base[g] = cmin;
+            }
+            __syncthreads();
+            if (inside && c - lowest >= kFarColumn) {
+                const uint32_t slot = (uint32_t)atomicAdd(far_count, 1);
+                if (slot < far_cap) far_entry[slot] = e[0];
+                key[0] = (uint32_t)kRowsPerBlock;      // sorts behind the entries that stay
+                e[0] = 0xffffffffu;
+            }
         }
         Sort(tmp).Sort(key, e, 0, kRowBits + 1);
-        if (key[0] < (uint32_t)kRowsPerBlock) {   // the empty lanes of a block's last chunk sort to its end
+        if (kPacked) {
+            if (e[0] != 0xffffffffu) {
+                tcol[q] = (key[0] << kColField) | ((uint32_t)col[e[0]] - lowest);
+                tval[q] = val[e[0]];
+            } else if (inside) {                       // the stream positions are the same set before and after the sort
+                tcol[q] = kFarColumn;
+                tval[q] = 0.0;
+            }
+        } else if (e[0] != 0xffffffffu) {
             trow[q] = (uint16_t)key[0];
             tcol[q] = (uint32_t)col[e[0]];
             tval[q] = val[e[0]];
@@ -103,14 +142,47 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
     }
 }
 
+// The entries the packed stream left out, in CRS order (far_entry sorted): a thread at the first
+// entry of a row adds the row's entries to y, which the tiled kernels have written before;
+// dots[workgroup] = xdot . (what it added).
+__global__ void __launch_bounds__(kBlock)
+k_tiles_far(int nfar, const uint32_t *__restrict__ far_entry, const int32_t *__restrict__ far_row,
+            const int32_t *__restrict__ col, const double *__restrict__ val, const double *__restrict__ x,
+            const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ dots) {
+    __shared__ double red[kBlock / 64];
+    const int t = (int)blockIdx.x * kBlock + (int)threadIdx.x;
+    double acc = 0.0;
+    if (t < nfar && (t == 0 || far_row[t - 1] != far_row[t])) {
+        const int r = far_row[t];
+        double sum = 0.0;
+        for (int j = t; j < nfar && far_row[j] == r; ++j) sum += val[far_entry[j]] * x[col[far_entry[j]]];
+        y[r] += sum;
+        acc = xdot[r] * sum;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) dots[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// far_row[t] = row of entry far_entry[t]
+__global__ void __launch_bounds__(kBlock)
+k_tiles_far_rows(int nfar, const uint32_t *__restrict__ far_entry, const int32_t *__restrict__ rowid,
+                 int32_t *__restrict__ far_row) {
+    const int t = (int)blockIdx.x * kBlock + (int)threadIdx.x;
+    if (t < nfar) far_row[t] = rowid[far_entry[t]];
+}
+
 // A workgroup takes piece piece0 + its own number and then, with draw set, draws further ones from
 // a counter (zero at launch) until none is left.  A piece that is a whole block writes
 // its rows of y and dots[piece] = xdot . y over them; a share of a block writes its sums to the side
 // buffer and dots[piece] = 0.
+template <bool kAhead, bool kPacked>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__restrict__ pieces,
              const uint32_t *__restrict__ block_ptr, const uint16_t *__restrict__ trow,
-             const uint32_t *__restrict__ tcol, const double *__restrict__ tval, const double *__restrict__ x,
+             const uint32_t *__restrict__ tcol, const uint32_t *__restrict__ tbase,
+             const double *__restrict__ tval, const double *__restrict__ x,
              const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ side,
              double *__restrict__ dots, int *__restrict__ counter) {
     __shared__ double ylds[kRowsPerBlock];
@@ -132,14 +204,51 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
         const uint32_t a = block_ptr[pc.block] + pc.chunk0 * (uint32_t)kBlock;
         const uint64_t stop = (uint64_t)a + (uint64_t)pc.chunks * kBlock;
         const uint32_t b = stop < (uint64_t)block_ptr[pc.block + 1] ? (uint32_t)stop : block_ptr[pc.block + 1];
+        // kAhead: the stream is read one chunk ahead of the gathers it feeds.  That pays where the
+        // workgroups wander through the panels on their own (+8 % on an R-MAT graph) and costs a quarter
+        // where they sweep in step and the L2s' request rate is the limit (random sparsity).
+        uint32_t cn = 0;
+        int rn = -1;
+        double vn = 0.0;
+        if (kAhead && a + tid < b) {
+            cn = __builtin_nontemporal_load(tcol + a + tid);
+            rn = (int)__builtin_nontemporal_load(trow + a + tid);
+            vn = __builtin_nontemporal_load(tval + a + tid);
+        }
+        uint32_t cbn = kPacked && a < b ? tbase[pc.gchunk0] : 0u;
         for (uint32_t q0 = a; q0 < b; q0 += kBlock) {
-            const uint32_t q = q0 + tid;
             int r = -1;
             double sum = 0.0;
-            if (q < b) {
-                const uint32_t c = __builtin_nontemporal_load(tcol + q);
-                r = (int)__builtin_nontemporal_load(trow + q);
-                sum = __builtin_nontemporal_load(tval + q) * x[c];
+            if (kAhead) {
+                r = rn;
+                const double xv = r >= 0 ? x[cn] : 0.0;
+                sum = vn;
+                const uint64_t qn = (uint64_t)q0 + kBlock + tid;
+                rn = -1;
+                if (qn < b) {
+                    cn = __builtin_nontemporal_load(tcol + qn);
+                    rn = (int)__builtin_nontemporal_load(trow + qn);
+                    vn = __builtin_nontemporal_load(tval + qn);
+                }
+                sum *= xv;
+            } else if (kPacked) {
+                uint32_t pk = kFarColumn;
+                double v = 0.0;
+                if (q0 + tid < b) {
+                    pk = __builtin_nontemporal_load(tcol + q0 + tid);
+                    v = __builtin_nontemporal_load(tval + q0 + tid);
+                }
+                const uint32_t cb = cbn;           // uniform: one base per chunk, read one chunk ahead
+                if (q0 + kBlock < b) cbn = tbase[pc.gchunk0 + (q0 - a) / kBlock + 1];
+                const uint32_t rel = pk & kFarColumn;
+                const bool live = rel != kFarColumn;       // else: no entry, or one that k_tiles_far adds afterwards
+                const double xv = live ? x[(uint64_t)cb + rel] : 0.0;
+                r = live ? (int)(pk >> kColField) : -1;
+                sum = v * xv;                              // v on both sides of the test: its load stays up here too
+            } else if (q0 + tid < b) {
+                const uint32_t c = __builtin_nontemporal_load(tcol + q0 + tid);
+                r = (int)__builtin_nontemporal_load(trow + q0 + tid);
+                sum = __builtin_nontemporal_load(tval + q0 + tid) * x[c];
             }
             // runs of equal rows inside the wavefront: after the scan a run's first lane holds its sum
             const int rprev = __shfl_up(r, 1);
@@ -240,6 +349,14 @@ void Engine::free_panels() {
     (void)hipFree(d_tside);
     (void)hipFree(d_tdots);
     (void)hipFree(d_tcounter);
+    (void)hipFree(d_tbase);
+    (void)hipFree(d_tfar_entry);
+    (void)hipFree(d_tfar_row);
+    d_tbase = nullptr;
+    d_tfar_entry = nullptr;
+    d_tfar_row = nullptr;
+    tile_nfar = 0;
+    tile_packed = false;
     d_tdots = nullptr;
     d_tcounter = nullptr;
     d_trow = nullptr;
@@ -341,11 +458,11 @@ int Engine::build_panels(int bits) {
         for (int64_t K = 0; K < nblocks; ++K) {
             const uint32_t c = (bp[K + 1] - bp[K] + kBlock - 1) / kBlock;
             if (c <= limit) {
-                pieces.push_back({(int32_t)K, 0u, (int32_t)c, -1});     // empty blocks too: their rows of y are zeros
+                pieces.push_back({(int32_t)K, 0u, (int32_t)c, -1, cf[K], 0u});   // empty blocks too: their rows of y are zeros
             } else {
                 splits.push_back({(int32_t)K, slots, 0, 0});
                 for (uint32_t c0 = 0; c0 < c; c0 += limit, ++slots, ++splits.back().count)
-                    pieces.push_back({(int32_t)K, c0, (int32_t)std::min<uint32_t>(limit, c - c0), slots});
+                    pieces.push_back({(int32_t)K, c0, (int32_t)std::min<uint32_t>(limit, c - c0), slots, cf[K] + c0, 0u});
             }
         }
         cf[nblocks] = (uint32_t)chunks;
@@ -357,15 +474,70 @@ int Engine::build_panels(int bits) {
     const uint32_t chunks = cf[nblocks];
     PN_TRY(hipMalloc(&d_chunk_first, sizeof(uint32_t) * (nblocks + 1)));
     PN_TRY(hipMemcpyAsync(d_chunk_first, cf.data(), sizeof(uint32_t) * (nblocks + 1), hipMemcpyHostToDevice, stream));
-    PN_TRY(hipMalloc(&d_trow, sizeof(uint16_t) * nnz));
     PN_TRY(hipMalloc(&d_tcol, sizeof(uint32_t) * nnz));
     PN_TRY(hipMalloc(&d_pval, sizeof(double) * nnz));
-    if (chunks > 0)
-        hipLaunchKernelGGL(k_tile_place, dim3((unsigned)std::min<uint32_t>(chunks, 65536u * 16u)), dim3(kBlock), 0, stream,
-                           chunks, nblocks, (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
-                           (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
-                           (const double *)d_val, d_trow, d_tcol, d_pval);
-    PN_TRY(hipGetLastError());
+    const unsigned pgrid = (unsigned)std::min<uint32_t>(std::max<uint32_t>(chunks, 1u), 65536u * 16u);
+    // Even blocks: try the 12-byte stream (row and chunk-relative column in one word) first; it holds
+    // when no chunk's columns span 2^20 or more.  Otherwise, and for uneven blocks whose chunks cross
+    // many small tiles, 14 bytes: value, column, row.
+    tile_packed = false;
+    if (tile_even && chunks > 0) {
+        int far = 0;
+        uint32_t *far_raw = nullptr;                        // unsorted, as the workgroups append them
+        PN_TRY(hipMalloc(&d_tbase, sizeof(uint32_t) * chunks));
+        PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
+        PN_TRY(hipMemsetAsync(d_tcounter, 0, sizeof(int), stream));
+        hipError_t st = hipMalloc(&far_raw, sizeof(uint32_t) * kFarCap);
+        if (st == hipSuccess) {
+            hipLaunchKernelGGL(k_tile_place<true>, dim3(pgrid), dim3(kBlock), 0, stream, chunks, nblocks,
+                               (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
+                               (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
+                               (const double *)d_val, (uint16_t *)nullptr, d_tcol, d_pval, d_tbase, d_tcounter, kFarCap,
+                               far_raw);
+            st = hipGetLastError();
+        }
+        if (st == hipSuccess) st = hipMemcpyAsync(&far, d_tcounter, sizeof(int), hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);
+        tile_packed = st == hipSuccess && far >= 0 && (uint32_t)far <= kFarCap;
+        if (tile_packed && far > 0) {                      // the far list in CRS order, with each entry's row
+            size_t sort_bytes = 0;
+            void *sort_tmp = nullptr;
+            st = hipMalloc(&d_tfar_entry, sizeof(uint32_t) * far);
+            if (st == hipSuccess) st = hipMalloc(&d_tfar_row, sizeof(int32_t) * far);
+            if (st == hipSuccess)
+                st = hipcub::DeviceRadixSort::SortKeys(nullptr, sort_bytes, far_raw, d_tfar_entry, far, 0, 32, stream);
+            if (st == hipSuccess) st = hipMalloc(&sort_tmp, sort_bytes ? sort_bytes : 1);
+            if (st == hipSuccess)
+                st = hipcub::DeviceRadixSort::SortKeys(sort_tmp, sort_bytes, far_raw, d_tfar_entry, far, 0, 32, stream);
+            if (st == hipSuccess) {
+                hipLaunchKernelGGL(k_tiles_far_rows, dim3((far + kBlock - 1) / kBlock), dim3(kBlock), 0, stream, far,
+                                   (const uint32_t *)d_tfar_entry, (const int32_t *)d_rowid, d_tfar_row);
+                st = hipGetLastError();
+            }
+            if (st == hipSuccess) st = hipStreamSynchronize(stream);
+            (void)hipFree(sort_tmp);
+        }
+        (void)hipFree(far_raw);
+        PN_TRY(st);
+        tile_nfar = tile_packed ? far : 0;
+        if (getenv("LANCZOS_HIP_VERBOSE"))
+            fprintf(stderr, "lanczos_hip: tiled SpMV, %u chunks, %d entries kept out of the packed stream%s\n", chunks,
+                    far, tile_packed ? "" : " (too many: unpacked form)");
+        if (!tile_packed) {
+            (void)hipFree(d_tbase);
+            d_tbase = nullptr;
+        }
+    }
+    if (!tile_packed) {
+        PN_TRY(hipMalloc(&d_trow, sizeof(uint16_t) * nnz));
+        if (chunks > 0)
+            hipLaunchKernelGGL(k_tile_place<false>, dim3(pgrid), dim3(kBlock), 0, stream, chunks, nblocks,
+                               (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
+                               (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
+                               (const double *)d_val, d_trow, d_tcol, d_pval, (uint32_t *)nullptr, (int *)nullptr, 0u,
+                               (uint32_t *)nullptr);
+        PN_TRY(hipGetLastError());
+    }
     PN_TRY(hipMalloc(&d_tpieces, sizeof(TilePiece) * std::max<size_t>(pieces.size(), 1)));
     PN_TRY(hipMemcpyAsync(d_tpieces, pieces.data(), sizeof(TilePiece) * pieces.size(), hipMemcpyHostToDevice, stream));
     if (!splits.empty()) {
@@ -373,8 +545,8 @@ int Engine::build_panels(int bits) {
         PN_TRY(hipMemcpyAsync(d_tsplits, splits.data(), sizeof(TileSplit) * splits.size(), hipMemcpyHostToDevice, stream));
         PN_TRY(hipMalloc(&d_tside, sizeof(double) * (size_t)slots * kRowsPerBlock));
     }
-    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + kCombineGroups)));
-    PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
+    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + kCombineGroups + kFarCap / kBlock)));
+    if (!d_tcounter) PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
     PN_TRY(hipStreamSynchronize(stream));
     cleanup();
 #undef PN_TRY
@@ -387,28 +559,40 @@ int Engine::build_panels(int bits) {
 }
 
 int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts) {
+#define TILES_ARGS(p0, draw)                                                                                         \
+    n, p0, tile_npieces, draw, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr, (const uint16_t *)d_trow,  \
+        (const uint32_t *)d_tcol, (const uint32_t *)d_tbase, (const double *)d_pval, x, xdot, y, d_tside, d_tdots,      \
+        d_tcounter
     if (tile_even) {
         // equal work in every piece: launches of kGroups workgroups that start together and sweep the
         // panels in step, so that an XCD's L2 holds one panel's slice of x at a time
-        for (int p0 = 0; p0 < tile_npieces; p0 += kGroups)
-            hipLaunchKernelGGL(k_spmv_tiles, dim3(std::min(kGroups, tile_npieces - p0)), dim3(kBlock), 0, stream, n, p0,
-                               tile_npieces, 0, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr,
-                               (const uint16_t *)d_trow, (const uint32_t *)d_tcol, (const double *)d_pval, x, xdot, y,
-                               d_tside, d_tdots, d_tcounter);
+        for (int p0 = 0; p0 < tile_npieces; p0 += kGroups) {
+            const dim3 grid(std::min(kGroups, tile_npieces - p0));
+            if (tile_packed)
+                hipLaunchKernelGGL((k_spmv_tiles<false, true>), grid, dim3(kBlock), 0, stream, TILES_ARGS(p0, 0));
+            else
+                hipLaunchKernelGGL((k_spmv_tiles<false, false>), grid, dim3(kBlock), 0, stream, TILES_ARGS(p0, 0));
+        }
     } else {
         // uneven pieces, fullest blocks first: one launch whose workgroups draw pieces as they finish
         if (hipMemsetAsync(d_tcounter, 0, sizeof(int), stream) != hipSuccess)
             return fail("lanczos_hip: clearing the tiled SpMV's piece counter failed");
-        hipLaunchKernelGGL(k_spmv_tiles, dim3(std::min(kGroups, tile_npieces)), dim3(kBlock), 0, stream, n, 0,
-                           tile_npieces, 1, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr,
-                           (const uint16_t *)d_trow, (const uint32_t *)d_tcol, (const double *)d_pval, x, xdot, y, d_tside,
-                           d_tdots, d_tcounter);
+        hipLaunchKernelGGL((k_spmv_tiles<true, false>), dim3(std::min(kGroups, tile_npieces)), dim3(kBlock), 0, stream,
+                           TILES_ARGS(0, 1));
     }
+#undef TILES_ARGS
     int count = tile_npieces;
     if (tile_nsplit > 0) {
         hipLaunchKernelGGL(k_tiles_combine, dim3(kCombineGroups), dim3(kBlock), 0, stream, n, tile_nsplit,
                            (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces);
         count += kCombineGroups;
+    }
+    if (tile_nfar > 0) {
+        const int groups = (tile_nfar + kBlock - 1) / kBlock;
+        hipLaunchKernelGGL(k_tiles_far, dim3(groups), dim3(kBlock), 0, stream, tile_nfar, (const uint32_t *)d_tfar_entry,
+                           (const int32_t *)d_tfar_row, (const int32_t *)d_col, (const double *)d_val, x, xdot, y,
+                           d_tdots + count);
+        count += groups;
     }
     hipLaunchKernelGGL(k_tiles_fold, dim3(1), dim3(kBlock), 0, stream, count, (const double *)d_tdots, d_partials);
     *nparts = kBlock;

@@ -255,6 +255,23 @@ def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
         assert e.spmv_name == "dict27"
 
 
+@pytest.mark.parametrize("log2n", [24, 25])
+def test_panel_spmv_far_columns(gpu, log2n):
+    """Even row blocks whose chunks reach across 2^20 columns and more: a few entries per chunk keep their
+    column in the side list of the packed stream (2^24 rows), or the unpacked stream is built (2^25 rows:
+    more such entries than the list holds).  One random entry per row, checked against direct evaluation."""
+    n = 1 << log2n
+    rng = np.random.default_rng(log2n)
+    cols = rng.integers(0, n, n).astype(np.int64)
+    vals = rng.standard_normal(n)
+    a = la.CrsMatrix(vals, cols, np.arange(n + 1, dtype=np.int64))
+    x = rng.standard_normal(n)
+    with la.Engine(a, 3, reorth="none", spmv="panel") as e:
+        y = e.spmv(x)
+        assert e.spmv(x).tobytes() == y.tobytes()
+    assert np.array_equal(y, vals * x[cols])
+
+
 def test_panel_spmv_on_power_law_graph(gpu, monkeypatch):
     """The tiled form on hub rows: the fullest row blocks are cut into pieces whose sums a second kernel
     adds in order; same products as the row-wise oracle (src/crs.c:155-178), same Lanczos sequences,
