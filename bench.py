@@ -54,6 +54,8 @@ def parse_args():
     ap.add_argument("--rand-rows", type=int, default=10_000_000,
                     help="rows of the random symmetric matrix (~21 entries per row) of the secondary section; "
                          "50000000 is the full-size configuration, 0 skips the section")
+    ap.add_argument("--rmat-scale", type=int, default=24,
+                    help="scale of the R-MAT graph Laplacian section (n = 2^scale; 26 is the full configuration; 0 skips it)")
     ap.add_argument("--big-grid", type=int, default=512,
                     help="grid size N of the N^3 Laplacian of the strong-scaling section (SpMV + vector step, "
                          "no reorthogonalisation: the basis of 300 vectors would not fit one GPU); 0 skips it")
@@ -187,6 +189,58 @@ def random_symmetric_section(la, torch, rows: int, steps: int = 100) -> dict:
         "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
         "generate_s": t_gen,
     }
+
+
+def power_law_section(la, torch, scale: int, steps: int = 50, block_steps: int = 3) -> dict:
+    """Power-law rows: the graph Laplacian of an R-MAT graph (edge factor 16, a/b/c = 0.57/0.19/0.19),
+    drawn on the GPU.  The SpMV + vector step of the single-vector path, and block steps of the 16-column
+    variant (fp64 matrix-core reorthogonalisation) on the same matrix."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+    from matrices import rmat_laplacian_gpu
+    t0 = time.perf_counter()
+    a = la.CrsMatrix(*rmat_laplacian_gpu(scale))
+    t_gen = time.perf_counter() - t0
+    n, nnz = a.dimension, a.length
+    b = algorithmic_bytes(n, nnz)
+    with la.Engine(a, 4, reorth="none", profile=True) as e:
+        e.set_start_seed(123456789)
+        e.run(3)
+        e.profile_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e.run(steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = e.profile()
+        name = e.spmv_name
+    out = {
+        "workload": f"R-MAT scale {scale} graph Laplacian, n={n}, nnz={nnz}, longest row "
+                    f"{int(np.diff(a.row_head_indexes).max())}",
+        "steps": steps,
+        "iters_per_s": steps / dt,
+        "ms_per_iter": dt / steps * 1e3,
+        "algorithmic_bytes_per_iter": b["iter"],
+        "frac_of_hbm_peak": b["iter"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
+        "spmv_kernel": name,
+        "spmv_avg_ms": prof["spmv"]["ms"] / steps,
+        "spmv_G_entries_per_s": nnz * steps / (prof["spmv"]["ms"] * 1e-3) / 1e9,
+        "generate_s": t_gen,
+    }
+    if block_steps > 0:
+        with la.BlockEngine(a, block_steps, profile=True) as be:
+            be.set_start_seed(1)
+            be.run(1)
+            be.set_start_seed(1)
+            be.profile_reset()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            be.run(block_steps)
+            torch.cuda.synchronize()
+            dtb = time.perf_counter() - t0
+            pb = be.profile()
+        out["block_variant"] = {"block_steps": block_steps, "ms_per_block_step": dtb / block_steps * 1e3,
+                                "kernel_ms_per_step": {k: v["ms"] / block_steps for k, v in pb.items()}}
+    return out
 
 
 def big_laplacian_section(la, torch, N: int, steps: int = 100) -> dict:
@@ -426,6 +480,8 @@ def single_gpu(args) -> dict:
         out["block_variant"] = block_variant(la, a)
     if args.rand_rows > 0:
         out["random_symmetric"] = random_symmetric_section(la, torch, args.rand_rows)
+    if args.rmat_scale > 0:
+        out["power_law_graph"] = power_law_section(la, torch, args.rmat_scale)
     if not args.no_cpu_baseline:
         cb = cpu_baseline(a, v0, args.cpu_steps)
         s = min(cb["steps"], K)
@@ -487,7 +543,7 @@ def main():
     args = parse_args()
     if args.main_only:
         args.no_block = args.no_cpu_baseline = True
-        args.rand_rows = args.big_grid = args.converge_steps = 0
+        args.rand_rows = args.big_grid = args.converge_steps = args.rmat_scale = 0
     if (args.gpus > 1 or args.force_dist) and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args, sys.argv[1:]))
     # stdout carries the one JSON line and nothing else: whatever libraries print while the run
