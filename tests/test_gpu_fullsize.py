@@ -133,6 +133,30 @@ def test_random_symmetric_50m_rows(gpu):
     print(f"[{time.perf_counter() - t0:.0f}s] done", flush=True)
 
 
+def test_rmat_scale_23_first_steps_against_the_oracle(gpu):
+    """The size at which the engine hands power-law graphs to the tiled SpMV by itself (n = 2^23, 64 MiB of x,
+    263M entries): the product and the first steps of the recurrence against the CPU restatement of
+    src/crs.c:155-178 and src/lanczos.c."""
+    from matrices import rmat_laplacian_gpu
+    a = la.CrsMatrix(*rmat_laplacian_gpu(23))
+    n = a.dimension
+    x = np.random.default_rng(5).standard_normal(n)
+    want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+    v0 = la.gaussian_fill(123456789, 0, n)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 2, 5, 0.0, "none")
+    with la.Engine(a, 8, reorth="none") as e:
+        assert e.spmv_name == "panel12"
+        y = e.spmv(x)
+        # a hub row sums 2.6e5 products; the bound scales with sum |a_ij x_j| per row
+        bound = 1e-13 * (1.0 + oracle.matvec_crs(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x)))
+        assert np.all(np.abs(y - want) <= bound)
+        assert e.spmv(x).tobytes() == y.tobytes()
+        e.set_start(v0)
+        alpha, beta = e.run(4)
+    assert np.max(np.abs(alpha - o.alpha) / np.abs(o.alpha)) < 1e-11
+    assert np.max(np.abs(beta - o.beta) / np.abs(o.beta)) < 1e-11
+
+
 def test_rmat_scale_26_graph_laplacian(gpu):
     """The power-law configuration at its full size (R-MAT scale 26, edge factor 16: n = 67 108 864, more
     than 2^31 entries, longest row about a million entries, half of the vertices isolated): L * ones = 0
