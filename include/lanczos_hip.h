@@ -325,7 +325,7 @@ void lanczos_hip_profile_reset(lanczos_hip_engine *e);
  * repeat as at most 65535 patterns, else "rows" if every 64-row group fits one tile; otherwise
  * "panel" when the sampled rows reach across more than 16 MiB of the vector; when the fullest
  * 64-row group holds 16 times the average, "panel" (narrow panels, split row blocks) if the vector
- * exceeds 40 MiB and "merge" below that; else "pipe". */
+ * exceeds 6 MiB and the sampled rows reach across 2 MiB of it, else "merge"; else "pipe". */
 const char *lanczos_hip_spmv_name(const lanczos_hip_engine *e);
 
 /*

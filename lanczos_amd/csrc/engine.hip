@@ -333,11 +333,13 @@ int Engine::choose_spmv(int requested) {
         } else {
             // rows that reach across more of x than the L2s hold (the sampled rows' mean column
             // extent against 16 MiB of doubles, half the L2s): gathers would each fetch a line from memory
-            // With uneven rows the share-of-entries form (below) holds up while x fits the caches behind
-            // the L2s; the tiled form takes over beyond 40 MiB of x (measured on R-MAT graphs: 1.43 against
-            // 1.65 ms at n = 2^22, 8.4 against 5.3 ms at 2^24, 45 against 21 ms at 2^26).
+            // With uneven rows the share-of-entries form (below) is the faster one while x is a few MiB; the
+            // tiled form takes over from about 6 MiB of x (measured on R-MAT graphs, merge against tiled:
+            // 0.079 / 0.123 ms at n = 2^18, 0.143 / 0.137 at 2^19, 0.337 / 0.250 at 2^20, 1.43 / 0.94 at 2^22,
+            // 8.4 / 3.8 at 2^24, 45 / 17.7 at 2^26), provided the sampled rows reach across 2 MiB of it and more
+            // (half the rows of such a graph hold the diagonal alone and count with extent 0).
             const double extent = stats[3] ? (double)stats[4] / (double)stats[3] : 0.0;
-            const bool tiled = uneven ? extent * 8.0 > 8.0 * 1048576.0 && 8.0 * (double)n_ext > 40.0 * 1048576.0
+            const bool tiled = uneven ? extent * 8.0 > 2.0 * 1048576.0 && 8.0 * (double)n_ext > 6.0 * 1048576.0
                                       : extent * 8.0 > 16.0 * 1048576.0;
             if (tiled && mean >= 2.0) {
                 if (int rc = build_panels(panel_bits)) return rc;

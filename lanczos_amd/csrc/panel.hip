@@ -36,7 +36,6 @@ static constexpr int kRowBits = 12;             // rows per block = 4096 (32 KiB
 static constexpr int kRowsPerBlock = 1 << kRowBits;
 static constexpr int kPieceChunks = 512;        // chunks of 256 entries in one piece at most (131 072 entries)
 static constexpr int kGroups = 1024;            // 4 workgroups per CU, all resident together; they draw pieces in order
-static constexpr int kCombineGroups = 256;      // workgroups that add up the pieces of split blocks
 
 // slot < 0: the piece is its whole block and writes y; else it writes sums to side-buffer slot `slot`
 struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; uint32_t gchunk0; uint32_t unused; };
@@ -307,23 +306,30 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
     }
 }
 
-// y of the split blocks: their pieces' sums added in piece order; dots[workgroup] = its xdot . y
+// y of the split blocks: their pieces' sums added in piece order.  A workgroup takes 256 rows of one
+// split block, a thread one row (loads four pieces ahead, adds in order); dots[workgroup] = its xdot . y
+static constexpr int kCombineParts = kRowsPerBlock / kBlock;
 __global__ void __launch_bounds__(kBlock)
-k_tiles_combine(int64_t n, int nsplit, const TileSplit *__restrict__ splits, const double *__restrict__ side,
+k_tiles_combine(int64_t n, const TileSplit *__restrict__ splits, const double *__restrict__ side,
                 const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ dots) {
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x;
+    const TileSplit sp = splits[blockIdx.x / kCombineParts];
+    const int i = (int)(blockIdx.x % kCombineParts) * kBlock + tid;
+    const int64_t row = ((int64_t)sp.block << kRowBits) + i;
+    const double *src = side + (int64_t)sp.slot0 * kRowsPerBlock + i;
+    double v = 0.0;
+    int p = 0;
+    for (; p + 4 <= sp.count; p += 4) {
+        const double a0 = src[(int64_t)p * kRowsPerBlock], a1 = src[(int64_t)(p + 1) * kRowsPerBlock];
+        const double a2 = src[(int64_t)(p + 2) * kRowsPerBlock], a3 = src[(int64_t)(p + 3) * kRowsPerBlock];
+        v = (((v + a0) + a1) + a2) + a3;
+    }
+    for (; p < sp.count; ++p) v += src[(int64_t)p * kRowsPerBlock];
     double acc = 0.0;
-    for (int m = blockIdx.x; m < nsplit; m += gridDim.x) {
-        const TileSplit sp = splits[m];
-        const int64_t row0 = (int64_t)sp.block << kRowBits;
-        for (int i = tid; i < kRowsPerBlock; i += kBlock)
-            if (row0 + i < n) {
-                double v = 0.0;
-                for (int p = 0; p < sp.count; ++p) v += side[(int64_t)(sp.slot0 + p) * kRowsPerBlock + i];
-                y[row0 + i] = v;
-                acc += xdot[row0 + i] * v;
-            }
+    if (row < n) {
+        y[row] = v;
+        acc = xdot[row] * v;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((tid & 63) == 0) red[tid >> 6] = acc;
@@ -335,7 +341,13 @@ k_tiles_combine(int64_t n, int nsplit, const TileSplit *__restrict__ splits, con
 __global__ void __launch_bounds__(kBlock)
 k_tiles_fold(int count, const double *__restrict__ dots, double *__restrict__ partials) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += kBlock) s += dots[i];
+    for (int i = threadIdx.x; i < count; i += 8 * kBlock) {      // eight loads in flight, added in index order
+        double a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = i + u * kBlock < count ? dots[i + u * kBlock] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+    }
     partials[threadIdx.x] = s;
 }
 
@@ -545,7 +557,7 @@ int Engine::build_panels(int bits) {
         PN_TRY(hipMemcpyAsync(d_tsplits, splits.data(), sizeof(TileSplit) * splits.size(), hipMemcpyHostToDevice, stream));
         PN_TRY(hipMalloc(&d_tside, sizeof(double) * (size_t)slots * kRowsPerBlock));
     }
-    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + kCombineGroups + kFarCap / kBlock)));
+    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + splits.size() * kCombineParts + kFarCap / kBlock)));
     if (!d_tcounter) PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
     PN_TRY(hipStreamSynchronize(stream));
     cleanup();
@@ -583,9 +595,9 @@ int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, i
 #undef TILES_ARGS
     int count = tile_npieces;
     if (tile_nsplit > 0) {
-        hipLaunchKernelGGL(k_tiles_combine, dim3(kCombineGroups), dim3(kBlock), 0, stream, n, tile_nsplit,
+        hipLaunchKernelGGL(k_tiles_combine, dim3(tile_nsplit * kCombineParts), dim3(kBlock), 0, stream, n,
                            (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces);
-        count += kCombineGroups;
+        count += tile_nsplit * kCombineParts;
     }
     if (tile_nfar > 0) {
         const int groups = (tile_nfar + kBlock - 1) / kBlock;
