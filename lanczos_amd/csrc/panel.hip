@@ -203,33 +203,45 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
         const uint32_t a = block_ptr[pc.block] + pc.chunk0 * (uint32_t)kBlock;
         const uint64_t stop = (uint64_t)a + (uint64_t)pc.chunks * kBlock;
         const uint32_t b = stop < (uint64_t)block_ptr[pc.block + 1] ? (uint32_t)stop : block_ptr[pc.block + 1];
-        // kAhead: the stream is read one chunk ahead of the gathers it feeds.  That pays where the
-        // workgroups wander through the panels on their own (+8 % on an R-MAT graph) and costs a quarter
-        // where they sweep in step and the L2s' request rate is the limit (random sparsity).
+        // kAhead: a two-stage pipeline -- while a chunk is summed, the next chunk's gathers and the stream
+        // of the one after it are in flight.  That pays where the workgroups wander through the panels on
+        // their own (+8 % and +4-13 % on R-MAT graphs) and costs a quarter where they sweep in step and the
+        // L2s' request rate is the limit (random sparsity).
         uint32_t cn = 0;
-        int rn = -1;
-        double vn = 0.0;
-        if (kAhead && a + tid < b) {
-            cn = __builtin_nontemporal_load(tcol + a + tid);
-            rn = (int)__builtin_nontemporal_load(trow + a + tid);
-            vn = __builtin_nontemporal_load(tval + a + tid);
+        int rn = -1, rc = -1;
+        double vn = 0.0, vc = 0.0, xg = 0.0;
+        if (kAhead) {                          // chunk 0: stream and gather; chunk 1: stream
+            if (a + tid < b) {
+                cn = __builtin_nontemporal_load(tcol + a + tid);
+                rc = (int)__builtin_nontemporal_load(trow + a + tid);
+                vc = __builtin_nontemporal_load(tval + a + tid);
+                xg = x[cn];
+            }
+            if ((uint64_t)a + kBlock + tid < b) {
+                cn = __builtin_nontemporal_load(tcol + a + kBlock + tid);
+                rn = (int)__builtin_nontemporal_load(trow + a + kBlock + tid);
+                vn = __builtin_nontemporal_load(tval + a + kBlock + tid);
+            }
         }
         uint32_t cbn = kPacked && a < b ? tbase[pc.gchunk0] : 0u;
         for (uint32_t q0 = a; q0 < b; q0 += kBlock) {
             int r = -1;
             double sum = 0.0;
             if (kAhead) {
-                r = rn;
-                const double xv = r >= 0 ? x[cn] : 0.0;
-                sum = vn;
-                const uint64_t qn = (uint64_t)q0 + kBlock + tid;
+                // this chunk's products; then the next chunk's gathers and the stream of the one after it go
+                // out, to be in flight while this chunk is summed
+                r = rc;
+                sum = vc * xg;
+                rc = rn;
+                vc = vn;
+                xg = rc >= 0 ? x[cn] : 0.0;
+                const uint64_t qn = (uint64_t)q0 + 2 * kBlock + tid;
                 rn = -1;
                 if (qn < b) {
                     cn = __builtin_nontemporal_load(tcol + qn);
                     rn = (int)__builtin_nontemporal_load(trow + qn);
                     vn = __builtin_nontemporal_load(tval + qn);
                 }
-                sum *= xv;
             } else if (kPacked) {
                 uint32_t pk = kFarColumn;
                 double v = 0.0;
