@@ -589,7 +589,8 @@ int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, i
         d_tcounter
     if (tile_even) {
         // equal work in every piece: launches of kGroups workgroups that start together and sweep the
-        // panels in step, so that an XCD's L2 holds one panel's slice of x at a time
+        // panels in step, so that an XCD's L2 holds one panel's slice of x at a time (one launch whose
+        // workgroups draw the pieces as they finish loses that: 15.4 against 9.3 ms at 50M rows)
         for (int p0 = 0; p0 < tile_npieces; p0 += kGroups) {
             const dim3 grid(std::min(kGroups, tile_npieces - p0));
             if (tile_packed)
