@@ -103,6 +103,8 @@ typedef struct crs {
  *                          around the copies, as src/lanczos_cuda.c:144, 168 do)
  *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 16; 12 on matrices
  *                          with wildly uneven rows)
+ *   LANCZOS_HIP_TILE_EVEN  1 / 0 forces the tiled SpMV's schedule for even / uneven row blocks (tests; by
+ *                          default the row blocks' weights decide)
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up found (chunks, entries kept out of the
  *                          packed stream) on stderr
  */

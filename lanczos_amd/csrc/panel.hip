@@ -477,6 +477,7 @@ int Engine::build_panels(int bits) {
         // at most `limit` chunks: half of a workgroup's share of the matrix, within [64, kPieceChunks], so
         // that no piece is a long pole.
         tile_even = nblocks >= kGroups / 4 && 4 * (uint64_t)most <= 5 * (chunks / (uint64_t)nblocks) + 8;
+        if (const char *force = getenv("LANCZOS_HIP_TILE_EVEN")) tile_even = atoi(force) != 0;   // for tests
         const uint32_t limit =
             tile_even ? most : (uint32_t)std::min<uint64_t>(kPieceChunks, std::max<uint64_t>(64, chunks / (2 * kGroups)));
         for (int64_t K = 0; K < nblocks; ++K) {

@@ -2,6 +2,7 @@
 the 16-column SpMM and the device COO->CRS conversion, each against a host evaluation (scipy for the
 products, numpy's stable sort for the conversion).  Prints one line per failure and a summary; exit
 status 1 when anything failed.  argv: [cases] [first seed]"""
+import os
 import sys
 import time
 
@@ -12,7 +13,9 @@ sys.path.insert(0, ".")
 import lanczos_amd as la
 
 CASES, SEED0 = 120, 0
-KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "dict"]
+# "panel/even" and "panel/drawn": the tiled form with its schedule forced (whole row blocks launched in step on
+# the packed stream / pieces drawn from a counter on the unpacked one), whatever the row blocks weigh
+KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "panel/even", "panel/drawn", "dict"]
 EPS = np.finfo(float).eps
 
 
@@ -76,8 +79,11 @@ def main():
         maxlen = int(np.diff(a.row_head_indexes).max())
         tol = (maxlen + 4) * EPS * (mabs @ np.abs(x)) + 1e-300
         for kind in KINDS:
+            os.environ.pop("LANCZOS_HIP_TILE_EVEN", None)
+            if "/" in kind:
+                os.environ["LANCZOS_HIP_TILE_EVEN"] = "1" if kind.endswith("even") else "0"
             try:
-                e = la.Engine(a, 3, spmv=kind)
+                e = la.Engine(a, 3, spmv=kind.split("/")[0])
             except la.LanczosHipError as ex:
                 if "needs" in str(ex):
                     declined += 1
