@@ -52,6 +52,24 @@ def test_loopback_slabs_match_the_single_engine_and_the_oracle(gpu, reorth):
         assert rel_err(la.ritz_values(a2, b2, cmp, 4), o.eigenvalues) < 1e-10, (reorth, slabs)
 
 
+@pytest.mark.parametrize("spmv", ["panel", "merge"])
+def test_loopback_slabs_on_the_gather_bound_forms(gpu, spmv):
+    """Slabs whose columns reach all over the vector (all-gather layout), on the tiled and the
+    share-of-entries SpMV: a random matrix and a power-law graph against the single engine."""
+    from matrices import rmat_laplacian
+    m16 = rmat_laplacian(14).tocsr()
+    graph = la.CrsMatrix(m16.data.astype(np.float64), m16.indices.astype(np.int64), m16.indptr.astype(np.int64))
+    for a in (la.synth_random_symmetric(30000, 8, 2), graph):
+        v0 = la.gaussian_fill(11, 0, a.dimension)
+        a1, b1 = single(a, v0, 30, "full")
+        with la.MultiEngine(a, 31, 3, reorth="full", spmv=spmv, loopback=True) as m:
+            assert m.info()["halo"] == 0
+            assert all(m.slab_spmv_name(s).startswith(spmv) for s in range(3))
+            m.set_start(v0)
+            a2, b2 = m.run(30)
+        assert rel_err(a2, a1) < 1e-11 and rel_err(b2, b1) < 1e-11, spmv
+
+
 def test_loopback_forced_allgather_and_unsplit_product(gpu, monkeypatch):
     a = la.synth_laplacian(3, 20)
     v0 = la.gaussian_fill(3, 0, a.dimension)
