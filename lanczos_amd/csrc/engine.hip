@@ -342,7 +342,9 @@ int Engine::choose_spmv(int requested) {
             const bool tiled = uneven ? extent * 8.0 > 2.0 * 1048576.0 && 8.0 * (double)n_ext > 6.0 * 1048576.0
                                       : extent * 8.0 > 16.0 * 1048576.0;
             if (tiled && mean >= 2.0) {
-                if (int rc = build_panels(panel_bits)) return rc;
+                // The regrouping needs about 20 bytes per entry of temporary device memory beside the 12-14
+                // it keeps; when that does not fit, the choice falls back to the row-wise forms below.
+                if (build_panels(panel_bits) != 0) (void)hipGetLastError();
                 if (tile_panels > 0) spmv_kind = LANCZOS_HIP_SPMV_PANEL;
             }
         }
