@@ -745,7 +745,8 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None
             try:
                 full = la.synth_laplacian(d, N)
                 res = {}
-                for mode, steps_m, warm in ((args.reorth, K, W), ("none", steps2, 5)):
+                runs = [(args.reorth, K, W)] + ([("none", steps2, 5)] if args.reorth != "none" else [])
+                for mode, steps_m, warm in runs:
                     with la.MultiEngine(full, max(steps_m, warm) + 1, world, reorth=mode) as m:
                         m.set_start_seed(123456789)
                         m.run(warm)
