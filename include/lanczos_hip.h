@@ -101,10 +101,12 @@ typedef struct crs {
  *   LANCZOS_HIP_NO_DICT    1 keeps the CRS kernels on matrices whose rows repeat
  *   LANCZOS_HIP_PIN_UPLOAD 0 uploads from pageable memory (default: the caller's arrays are page-locked
  *                          around the copies, as src/lanczos_cuda.c:144, 168 do)
- *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 16; 12 on matrices
+ *   LANCZOS_HIP_PANEL_BITS log2 of the column-panel width of the tiled SpMV (default 16; 10 on matrices
  *                          with wildly uneven rows)
  *   LANCZOS_HIP_TILE_EVEN  1 / 0 forces the tiled SpMV's schedule for even / uneven row blocks (tests; by
  *                          default the row blocks' weights decide)
+ *   LANCZOS_HIP_TILE_ROWBITS 12, 13 or 14: rows per block of the uneven schedule as a power of two (default 13,
+ *                          14 when the vector exceeds 256 MiB)
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up found (chunks, entries kept out of the
  *                          packed stream) on stderr
  */
@@ -160,7 +162,7 @@ enum {
                                     matrices); needs every 64-row group to hold <= 481 entries */
     LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
                                     caches (random sparsity, large power-law graphs): entries regrouped on
-                                    the device by (block of 4096 rows, column panel of 2^16 or 2^12 columns);
+                                    the device by (block of 4096 rows, column panel of 2^16 or 2^10 columns);
                                     a workgroup keeps its rows of y in LDS and sweeps the panels, whose slice
                                     of x stays in cache; row blocks too full for one workgroup are cut into
                                     pieces whose sums a second kernel adds in order.  Needs nnz < 2^32.

@@ -107,6 +107,7 @@ struct Engine {
     int *d_tcounter = nullptr;       // next piece to draw
     int tile_panels = 0, tile_bits = 16, panel_bits = 16;
     int tile_npieces = 0, tile_nsplit = 0, tile_nslots = 0;
+    int tile_rowbits = 12;           // log2 of the rows of a block: 12, 13 or 14
     bool tile_even = false;          // every piece carries about the same work
     // dictionary form of the matrix (LANCZOS_HIP_SPMV_DICT): one pattern number per row
     uint16_t *d_pattern = nullptr;
@@ -147,6 +148,8 @@ struct Engine {
     void free_dict();
     int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1);
     int build_panels(int bits);
+    template <int RB, int T>
+    int build_panels_shape(int bits, bool even);
     void free_panels();
     int launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts);
     int alloc_state();

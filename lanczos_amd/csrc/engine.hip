@@ -307,13 +307,14 @@ int Engine::choose_spmv(int requested) {
     const bool uneven = (double)max_span > 16.0 * 64.0 * std::max(mean, 1.0);
     bool bits_given = false;
     if (const char *s = getenv("LANCZOS_HIP_PANEL_BITS"))
-        if (atoi(s) >= 10 && atoi(s) <= 24) {
+        if (atoi(s) >= 6 && atoi(s) <= 24) {
             panel_bits = atoi(s);
             bits_given = true;
         }
     // narrow panels for power-law graphs: their tiles are small and the workgroups do not sweep in step,
-    // so what a panel's slice of x has to fit is a CU's share of the L2, not the L2
-    if (!bits_given && uneven) panel_bits = 12;
+    // so what a panel's slice of x has to fit is a CU's L1, not the L2 (R-MAT, 2^24 / 2^26 rows, ms per
+    // SpMV: 2^14 3.52 / 15.3, 2^12 3.13 / 14.0, 2^10 3.04 / 13.7, 2^8 3.02 / 13.5)
+    if (!bits_given && uneven) panel_bits = 10;
     const bool no_dict = getenv("LANCZOS_HIP_NO_DICT") && atoi(getenv("LANCZOS_HIP_NO_DICT")) != 0;
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO && !no_dict && stats[1] > 0 && 2 * stats[2] > stats[1]) {
         // neighbouring rows hold neighbouring columns: rows are likely to repeat as patterns
@@ -394,7 +395,7 @@ int Engine::choose_spmv(int requested) {
     else if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
         snprintf(spmv_name, sizeof(spmv_name), "dict%d", dict_patterns);
     else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
-        snprintf(spmv_name, sizeof(spmv_name), "panel%d%s", panel_bits, rp64 ? "_rp64" : "");
+        snprintf(spmv_name, sizeof(spmv_name), "panel%d%s", tile_bits, rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
         snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)

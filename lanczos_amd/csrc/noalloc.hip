@@ -76,10 +76,10 @@ int Engine::spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev) {
         return fail("lanczos_hip_spmv_noalloc: the matrix has %lld entries; on the merge SpMV this entry point takes "
                     "at most %lld (fixed scratch of %zu bytes)",
                     (long long)nnz, (long long)(kMaxMergeTiles * kMergeTile), kScratchBytes);
-    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL && (int64_t)tile_nslots * 4096 > 2 * kMaxMergeTiles)
+    if (spmv_kind == LANCZOS_HIP_SPMV_PANEL && ((int64_t)tile_nslots << tile_rowbits) > 2 * kMaxMergeTiles)
         return fail("lanczos_hip_spmv_noalloc: the tiled SpMV of this matrix cuts its fullest row blocks into %d pieces; "
                     "this entry point takes at most %lld (fixed scratch of %zu bytes)",
-                    tile_nslots, (long long)(2 * kMaxMergeTiles / 4096), kScratchBytes);
+                    tile_nslots, (long long)((2 * kMaxMergeTiles) >> tile_rowbits), kScratchBytes);
     Scratch *s = nullptr;
     if (int rc = scratch_for_device(device, &s)) return rc;
     // The kernels take their scratch as arguments; hand them the fixed array for this one launch.

@@ -31,11 +31,17 @@
 
 namespace lz {
 
-static constexpr int kBlock = 256;
-static constexpr int kRowBits = 12;             // rows per block = 4096 (32 KiB of y in LDS)
-static constexpr int kRowsPerBlock = 1 << kRowBits;
-static constexpr int kPieceChunks = 512;        // chunks of 256 entries in one piece at most (131 072 entries)
-static constexpr int kGroups = 1024;            // 4 workgroups per CU, all resident together; they draw pieces in order
+static constexpr int kBlock = 256;              // threads of the small kernels (keys, bounds, combine, far, fold)
+static constexpr int kPieceEntries = 131072;    // entries in one piece at most (four times as many with 16384-row blocks)
+// Three shapes of a workgroup's row block, RB = log2(rows), T = threads = entries per chunk; the y block is
+// 8 << RB bytes of LDS, and kGroups(RB) workgroups (16 wavefronts per CU) are resident together:
+//   RB 12, T  256   32 KiB, 4 per CU   even blocks (the packed word has 12 bits for the row)
+//   RB 13, T  512   64 KiB, 2 per CU   uneven blocks
+//   RB 14, T 1024  128 KiB, 1 per CU   uneven blocks, x beyond the memory-side cache (256 MiB)
+// Taller blocks put more of a block's entries into each panel, so more gathers share a sector: on R-MAT
+// graphs 8192 rows are worth 10 % at 2^24 rows and 16384 rows 20 % at 2^26, where the tiled SpMV is bound
+// by the sectors its misses move; on even matrices they change nothing (LDS holds as many rows either way).
+static constexpr int kGroups(int rb) { return 1024 >> (rb - 12); }
 
 // slot < 0: the piece is its whole block and writes y; else it writes sums to side-buffer slot `slot`
 struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; uint32_t gchunk0; uint32_t unused; };
@@ -46,12 +52,12 @@ struct TileSplit { int32_t block; int32_t slot0; int32_t count; int32_t unused; 
 
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
-k_tile_keys(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, int bits, int jbits,
+k_tile_keys(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, int rowbits, int bits, int jbits,
             uint32_t *__restrict__ keys, uint32_t *__restrict__ idx, int32_t *__restrict__ rowid) {
     const int64_t step = (int64_t)gridDim.x * kBlock;
     for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step)
         for (int64_t e = (int64_t)rp[r]; e < (int64_t)rp[r + 1]; ++e) {
-            keys[e] = ((uint32_t)(r >> kRowBits) << jbits) | ((uint32_t)col[e] >> bits);
+            keys[e] = ((uint32_t)(r >> rowbits) << jbits) | ((uint32_t)col[e] >> bits);
             idx[e] = (uint32_t)e;
             rowid[e] = (int32_t)r;
         }
@@ -80,16 +86,16 @@ k_block_bounds(int64_t nnz, const uint32_t *__restrict__ keys, int64_t nblocks, 
 // base[chunk] with base the chunk's smallest column.  An entry 2^20 - 1 or more columns away from it
 // does not fit: its number goes to the far list (*far_count counts them, also beyond far_cap), and
 // its place in the stream, after the chunk's other entries, holds kFarColumn, which the product skips.
-template <bool kPacked>
-__global__ void __launch_bounds__(kBlock)
+template <bool kPacked, int RB, int T>
+__global__ void __launch_bounds__(T)
 k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chunk_first,
              const uint32_t *__restrict__ block_ptr, const uint32_t *__restrict__ idx,
              const int32_t *__restrict__ rowid, const int32_t *__restrict__ col, const double *__restrict__ val,
              uint16_t *__restrict__ trow, uint32_t *__restrict__ tcol, double *__restrict__ tval,
              uint32_t *__restrict__ base, int *__restrict__ far_count, uint32_t far_cap,
              uint32_t *__restrict__ far_entry) {
-    using Sort = hipcub::BlockRadixSort<uint32_t, kBlock, 1, uint32_t>;
-    using Reduce = hipcub::BlockReduce<uint32_t, kBlock>;
+    using Sort = hipcub::BlockRadixSort<uint32_t, T, 1, uint32_t>;
+    using Reduce = hipcub::BlockReduce<uint32_t, T>;
     __shared__ typename Sort::TempStorage tmp;
     __shared__ typename Reduce::TempStorage rtmp;
     __shared__ uint32_t lowest;
@@ -100,13 +106,13 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
             if (chunk_first[mid] <= g) lo = mid;
             else hi = mid;
         }
-        const uint32_t q = block_ptr[lo] + (g - chunk_first[lo]) * (uint32_t)kBlock + threadIdx.x;
+        const uint32_t q = block_ptr[lo] + (g - chunk_first[lo]) * (uint32_t)T + threadIdx.x;
         const bool inside = q < block_ptr[lo + 1];     // false in the empty lanes of a block's last chunk
-        uint32_t key[1] = {(uint32_t)kRowsPerBlock}, e[1] = {0xffffffffu};
+        uint32_t key[1] = {(uint32_t)(1 << RB)}, e[1] = {0xffffffffu};
         uint32_t c = 0;
         if (inside) {
             e[0] = idx[q];
-            key[0] = (uint32_t)rowid[e[0]] & (uint32_t)(kRowsPerBlock - 1);
+            key[0] = (uint32_t)rowid[e[0]] & (uint32_t)((1 << RB) - 1);
             c = (uint32_t)col[e[0]];
         }
         if (kPacked) {
@@ -119,11 +125,11 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
             if (inside && c - lowest >= kFarColumn) {
                 const uint32_t slot = (uint32_t)atomicAdd(far_count, 1);
                 if (slot < far_cap) far_entry[slot] = e[0];
-                key[0] = (uint32_t)kRowsPerBlock;      // sorts behind the entries that stay
+                key[0] = (uint32_t)(1 << RB);      // sorts behind the entries that stay
                 e[0] = 0xffffffffu;
             }
         }
-        Sort(tmp).Sort(key, e, 0, kRowBits + 1);
+        Sort(tmp).Sort(key, e, 0, RB + 1);
         if (kPacked) {
             if (e[0] != 0xffffffffu) {
                 tcol[q] = (key[0] << kColField) | ((uint32_t)col[e[0]] - lowest);
@@ -176,20 +182,20 @@ k_tiles_far_rows(int nfar, const uint32_t *__restrict__ far_entry, const int32_t
 // a counter (zero at launch) until none is left.  A piece that is a whole block writes
 // its rows of y and dots[piece] = xdot . y over them; a share of a block writes its sums to the side
 // buffer and dots[piece] = 0.
-template <bool kAhead, bool kPacked>
-__global__ void __launch_bounds__(kBlock)
+template <bool kAhead, bool kPacked, int RB, int T>
+__global__ void __launch_bounds__(T)
 k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__restrict__ pieces,
              const uint32_t *__restrict__ block_ptr, const uint16_t *__restrict__ trow,
              const uint32_t *__restrict__ tcol, const uint32_t *__restrict__ tbase,
              const double *__restrict__ tval, const double *__restrict__ x,
              const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ side,
              double *__restrict__ dots, int *__restrict__ counter) {
-    __shared__ double ylds[kRowsPerBlock];
-    __shared__ double wsum[kBlock / 64];     // per wavefront: sum of the run that starts at its lane 0,
-    __shared__ int wrow[kBlock / 64];        //   that run's row,
-    __shared__ int wfull[kBlock / 64];       //   whether the run fills the wavefront,
-    __shared__ int wlast[kBlock / 64];       //   and the row of its lane 63
-    __shared__ double red[kBlock / 64];
+    __shared__ double ylds[(1 << RB)];
+    __shared__ double wsum[T / 64];     // per wavefront: sum of the run that starts at its lane 0,
+    __shared__ int wrow[T / 64];        //   that run's row,
+    __shared__ int wfull[T / 64];       //   whether the run fills the wavefront,
+    __shared__ int wlast[T / 64];       //   and the row of its lane 63
+    __shared__ double red[T / 64];
     __shared__ int next;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     // the first piece is the workgroup's own number, the later ones are drawn; pi is kept in a scalar
@@ -198,10 +204,10 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
     while (pi < npieces) {
         double acc = 0.0;
         const TilePiece pc = pieces[pi];
-        for (int i = tid; i < kRowsPerBlock; i += kBlock) ylds[i] = 0.0;
+        for (int i = tid; i < (1 << RB); i += T) ylds[i] = 0.0;
         __syncthreads();
-        const uint32_t a = block_ptr[pc.block] + pc.chunk0 * (uint32_t)kBlock;
-        const uint64_t stop = (uint64_t)a + (uint64_t)pc.chunks * kBlock;
+        const uint32_t a = block_ptr[pc.block] + pc.chunk0 * (uint32_t)T;
+        const uint64_t stop = (uint64_t)a + (uint64_t)pc.chunks * T;
         const uint32_t b = stop < (uint64_t)block_ptr[pc.block + 1] ? (uint32_t)stop : block_ptr[pc.block + 1];
         // kAhead: a two-stage pipeline -- while a chunk is summed, the next chunk's gathers and the stream
         // of the one after it are in flight.  That pays where the workgroups wander through the panels on
@@ -217,14 +223,14 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
                 vc = __builtin_nontemporal_load(tval + a + tid);
                 xg = x[cn];
             }
-            if ((uint64_t)a + kBlock + tid < b) {
-                cn = __builtin_nontemporal_load(tcol + a + kBlock + tid);
-                rn = (int)__builtin_nontemporal_load(trow + a + kBlock + tid);
-                vn = __builtin_nontemporal_load(tval + a + kBlock + tid);
+            if ((uint64_t)a + T + tid < b) {
+                cn = __builtin_nontemporal_load(tcol + a + T + tid);
+                rn = (int)__builtin_nontemporal_load(trow + a + T + tid);
+                vn = __builtin_nontemporal_load(tval + a + T + tid);
             }
         }
         uint32_t cbn = kPacked && a < b ? tbase[pc.gchunk0] : 0u;
-        for (uint32_t q0 = a; q0 < b; q0 += kBlock) {
+        for (uint32_t q0 = a; q0 < b; q0 += T) {
             int r = -1;
             double sum = 0.0;
             if (kAhead) {
@@ -235,7 +241,7 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
                 rc = rn;
                 vc = vn;
                 xg = rc >= 0 ? x[cn] : 0.0;
-                const uint64_t qn = (uint64_t)q0 + 2 * kBlock + tid;
+                const uint64_t qn = (uint64_t)q0 + 2 * T + tid;
                 rn = -1;
                 if (qn < b) {
                     cn = __builtin_nontemporal_load(tcol + qn);
@@ -250,7 +256,7 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
                     v = __builtin_nontemporal_load(tval + q0 + tid);
                 }
                 const uint32_t cb = cbn;           // uniform: one base per chunk, read one chunk ahead
-                if (q0 + kBlock < b) cbn = tbase[pc.gchunk0 + (q0 - a) / kBlock + 1];
+                if (q0 + T < b) cbn = tbase[pc.gchunk0 + (q0 - a) / T + 1];
                 const uint32_t rel = pk & kFarColumn;
                 const bool live = rel != kFarColumn;       // else: no entry, or one that k_tiles_far adds afterwards
                 const double xv = live ? x[(uint64_t)cb + rel] : 0.0;
@@ -285,7 +291,7 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
             // a run that crosses wavefronts is added by its first part, which collects the others in order
             if (head && r >= 0 && !(lane == 0 && w > 0 && wlast[w - 1] == r)) {
                 if (end == 64)
-                    for (int v = w + 1; v < kBlock / 64 && wrow[v] == r; ++v) {
+                    for (int v = w + 1; v < T / 64 && wrow[v] == r; ++v) {
                         sum += wsum[v];
                         if (!wfull[v]) break;
                     }
@@ -294,23 +300,25 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
             __syncthreads();
         }
         if (pc.slot < 0) {
-            const int64_t row0 = (int64_t)pc.block << kRowBits;
-            for (int i = tid; i < kRowsPerBlock; i += kBlock)
+            const int64_t row0 = (int64_t)pc.block << RB;
+            for (int i = tid; i < (1 << RB); i += T)
                 if (row0 + i < n) {
                     const double v = ylds[i];
                     y[row0 + i] = v;
                     acc += xdot[row0 + i] * v;
                 }
         } else {
-            double *out = side + (int64_t)pc.slot * kRowsPerBlock;
-            for (int i = tid; i < kRowsPerBlock; i += kBlock) out[i] = ylds[i];
+            double *out = side + (int64_t)pc.slot * (1 << RB);
+            for (int i = tid; i < (1 << RB); i += T) out[i] = ylds[i];
         }
         // workgroup sum in a fixed order
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
         if (lane == 0) red[w] = acc;
         __syncthreads();
         if (tid == 0) {
-            dots[pi] = (red[0] + red[1]) + (red[2] + red[3]);
+            double t = 0.0;
+            for (int i = 0; i < T / 64; ++i) t += red[i];
+            dots[pi] = t;
             next = draw ? (int)gridDim.x + atomicAdd(counter, 1) : npieces;
         }
         __syncthreads();
@@ -320,24 +328,24 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
 
 // y of the split blocks: their pieces' sums added in piece order.  A workgroup takes 256 rows of one
 // split block, a thread one row (loads four pieces ahead, adds in order); dots[workgroup] = its xdot . y
-static constexpr int kCombineParts = kRowsPerBlock / kBlock;
+template <int RB>
 __global__ void __launch_bounds__(kBlock)
 k_tiles_combine(int64_t n, const TileSplit *__restrict__ splits, const double *__restrict__ side,
                 const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ dots) {
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x;
-    const TileSplit sp = splits[blockIdx.x / kCombineParts];
-    const int i = (int)(blockIdx.x % kCombineParts) * kBlock + tid;
-    const int64_t row = ((int64_t)sp.block << kRowBits) + i;
-    const double *src = side + (int64_t)sp.slot0 * kRowsPerBlock + i;
+    const TileSplit sp = splits[blockIdx.x / ((1 << RB) / kBlock)];
+    const int i = (int)(blockIdx.x % ((1 << RB) / kBlock)) * kBlock + tid;
+    const int64_t row = ((int64_t)sp.block << RB) + i;
+    const double *src = side + (int64_t)sp.slot0 * (1 << RB) + i;
     double v = 0.0;
     int p = 0;
     for (; p + 4 <= sp.count; p += 4) {
-        const double a0 = src[(int64_t)p * kRowsPerBlock], a1 = src[(int64_t)(p + 1) * kRowsPerBlock];
-        const double a2 = src[(int64_t)(p + 2) * kRowsPerBlock], a3 = src[(int64_t)(p + 3) * kRowsPerBlock];
+        const double a0 = src[(int64_t)p * (1 << RB)], a1 = src[(int64_t)(p + 1) * (1 << RB)];
+        const double a2 = src[(int64_t)(p + 2) * (1 << RB)], a3 = src[(int64_t)(p + 3) * (1 << RB)];
         v = (((v + a0) + a1) + a2) + a3;
     }
-    for (; p < sp.count; ++p) v += src[(int64_t)p * kRowsPerBlock];
+    for (; p < sp.count; ++p) v += src[(int64_t)p * (1 << RB)];
     double acc = 0.0;
     if (row < n) {
         y[row] = v;
@@ -394,18 +402,20 @@ void Engine::free_panels() {
     tile_npieces = tile_nsplit = tile_nslots = 0;
 }
 
-// Regroup the device CRS by (row block, column panel).  tile_panels > 0 afterwards when the form
-// was built; 0 when the matrix does not qualify (too many entries for 32-bit positions, or a key
-// wider than 32 bits).  Non-zero return on errors.
-int Engine::build_panels(int bits) {
-    free_panels();
-    if (bits > 24) bits = 24;
-    if (nnz == 0 || nnz >= ((int64_t)1 << 32) - kBlock) return 0;
-    const int panels = (int)(((n_ext - 1) >> bits) + 1);
-    const int64_t nblocks = (n + kRowsPerBlock - 1) >> kRowBits;
-    int jbits = 1, kbits = 1;
-    while ((1 << jbits) < panels) jbits++;
+// Regroup the device CRS by (row block of 1 << RB rows, column panel), chunks of T entries.  `even`: the
+// blocks stay whole and are launched in step (RB 12 only); else pieces are cut and drawn.
+template <int RB, int T>
+int Engine::build_panels_shape(int bits, bool even) {
+    constexpr int kRows = 1 << RB;
+    const int64_t nblocks = (n + kRows - 1) >> RB;
+    int jbits = 1, kbits = 1, panels = 0;
     while (((int64_t)1 << kbits) < nblocks) kbits++;
+    for (;; ++bits) {                  // wider panels when (row block, panel) does not fit the 32-bit sort key
+        panels = (int)(((n_ext - 1) >> bits) + 1);
+        jbits = 1;
+        while ((1 << jbits) < panels) jbits++;
+        if (jbits + kbits <= 32 || bits >= 24) break;
+    }
     if (jbits + kbits > 32) return 0;
     uint32_t *d_keys[2] = {nullptr, nullptr}, *d_idx[2] = {nullptr, nullptr}, *d_chunk_first = nullptr;
     int32_t *d_rowid = nullptr;
@@ -437,10 +447,10 @@ int Engine::build_panels(int bits) {
     const int rblocks = (int)std::min<int64_t>(max_blocks, (n + kBlock - 1) / kBlock);
     if (rp64)
         hipLaunchKernelGGL((k_tile_keys<int64_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int64_t *)d_rp,
-                           (const int32_t *)d_col, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
     else
         hipLaunchKernelGGL((k_tile_keys<int32_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int32_t *)d_rp,
-                           (const int32_t *)d_col, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
     PN_TRY(hipGetLastError());
     hipcub::DoubleBuffer<uint32_t> keys(d_keys[0], d_keys[1]);
     hipcub::DoubleBuffer<uint32_t> vals(d_idx[0], d_idx[1]);
@@ -455,7 +465,7 @@ int Engine::build_panels(int bits) {
     hipLaunchKernelGGL(k_block_bounds, dim3(bblocks), dim3(kBlock), 0, stream, nnz, (const uint32_t *)keys.Current(),
                        nblocks, jbits, d_tblock_ptr);
     PN_TRY(hipGetLastError());
-    // the pieces: whole blocks where they fit, shares of at most kPieceChunks chunks otherwise
+    // the pieces: whole blocks where they fit, shares of at most kPieceEntries entries otherwise
     std::vector<uint32_t> bp, cf;
     std::vector<TilePiece> pieces;
     std::vector<TileSplit> splits;
@@ -469,19 +479,21 @@ int Engine::build_panels(int bits) {
         uint32_t most = 0;
         for (int64_t K = 0; K < nblocks; ++K) {
             cf[K] = (uint32_t)chunks;
-            const uint32_t c = (bp[K + 1] - bp[K] + kBlock - 1) / kBlock;
+            const uint32_t c = (bp[K + 1] - bp[K] + T - 1) / T;
             chunks += c;
             most = std::max(most, c);
         }
-        // Blocks of about equal weight, and enough of them to go round, stay whole.  Otherwise a piece holds
-        // at most `limit` chunks: half of a workgroup's share of the matrix, within [64, kPieceChunks], so
-        // that no piece is a long pole.
-        tile_even = nblocks >= kGroups / 4 && 4 * (uint64_t)most <= 5 * (chunks / (uint64_t)nblocks) + 8;
-        if (const char *force = getenv("LANCZOS_HIP_TILE_EVEN")) tile_even = atoi(force) != 0;   // for tests
-        const uint32_t limit =
-            tile_even ? most : (uint32_t)std::min<uint64_t>(kPieceChunks, std::max<uint64_t>(64, chunks / (2 * kGroups)));
+        // Even blocks stay whole.  Otherwise a piece holds at most `limit` chunks: half of a workgroup's
+        // share of the matrix, between 16384 and kPieceEntries entries, so that no piece is a long pole.
+        tile_even = even;
+        // measured on R-MAT graphs: 2^17 entries with 8192-row blocks (2^16: -2 %, 2^18: -3 % at 2^24 rows),
+        // 2^19 with 16384-row blocks (2^17: -4 %, 2^16: -10 % at 2^26 rows)
+        const uint64_t piece_entries = RB == 14 ? 4 * (uint64_t)kPieceEntries : (uint64_t)kPieceEntries;
+        const uint32_t limit = even ? most
+                                    : (uint32_t)std::min<uint64_t>(piece_entries / T,
+                                                                   std::max<uint64_t>(16384 / T, chunks / (2 * kGroups(RB))));
         for (int64_t K = 0; K < nblocks; ++K) {
-            const uint32_t c = (bp[K + 1] - bp[K] + kBlock - 1) / kBlock;
+            const uint32_t c = (bp[K + 1] - bp[K] + T - 1) / T;
             if (c <= limit) {
                 pieces.push_back({(int32_t)K, 0u, (int32_t)c, -1, cf[K], 0u});   // empty blocks too: their rows of y are zeros
             } else {
@@ -506,7 +518,7 @@ int Engine::build_panels(int bits) {
     // when no chunk's columns span 2^20 or more.  Otherwise, and for uneven blocks whose chunks cross
     // many small tiles, 14 bytes: value, column, row.
     tile_packed = false;
-    if (tile_even && chunks > 0) {
+    if (RB == 12 && even && chunks > 0) {
         int far = 0;
         uint32_t *far_raw = nullptr;                        // unsorted, as the workgroups append them
         PN_TRY(hipMalloc(&d_tbase, sizeof(uint32_t) * chunks));
@@ -514,7 +526,7 @@ int Engine::build_panels(int bits) {
         PN_TRY(hipMemsetAsync(d_tcounter, 0, sizeof(int), stream));
         hipError_t st = hipMalloc(&far_raw, sizeof(uint32_t) * kFarCap);
         if (st == hipSuccess) {
-            hipLaunchKernelGGL(k_tile_place<true>, dim3(pgrid), dim3(kBlock), 0, stream, chunks, nblocks,
+            hipLaunchKernelGGL((k_tile_place<true, RB, T>), dim3(pgrid), dim3(T), 0, stream, chunks, nblocks,
                                (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
                                (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
                                (const double *)d_val, (uint16_t *)nullptr, d_tcol, d_pval, d_tbase, d_tcounter, kFarCap,
@@ -556,7 +568,7 @@ int Engine::build_panels(int bits) {
     if (!tile_packed) {
         PN_TRY(hipMalloc(&d_trow, sizeof(uint16_t) * nnz));
         if (chunks > 0)
-            hipLaunchKernelGGL(k_tile_place<false>, dim3(pgrid), dim3(kBlock), 0, stream, chunks, nblocks,
+            hipLaunchKernelGGL((k_tile_place<false, RB, T>), dim3(pgrid), dim3(T), 0, stream, chunks, nblocks,
                                (const uint32_t *)d_chunk_first, (const uint32_t *)d_tblock_ptr,
                                (const uint32_t *)vals.Current(), (const int32_t *)d_rowid, (const int32_t *)d_col,
                                (const double *)d_val, d_trow, d_tcol, d_pval, (uint32_t *)nullptr, (int *)nullptr, 0u,
@@ -568,19 +580,61 @@ int Engine::build_panels(int bits) {
     if (!splits.empty()) {
         PN_TRY(hipMalloc(&d_tsplits, sizeof(TileSplit) * splits.size()));
         PN_TRY(hipMemcpyAsync(d_tsplits, splits.data(), sizeof(TileSplit) * splits.size(), hipMemcpyHostToDevice, stream));
-        PN_TRY(hipMalloc(&d_tside, sizeof(double) * (size_t)slots * kRowsPerBlock));
+        PN_TRY(hipMalloc(&d_tside, sizeof(double) * (size_t)slots * kRows));
     }
-    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + splits.size() * kCombineParts + kFarCap / kBlock)));
+    PN_TRY(hipMalloc(&d_tdots, sizeof(double) * (pieces.size() + splits.size() * (kRows / kBlock) + kFarCap / kBlock)));
     if (!d_tcounter) PN_TRY(hipMalloc(&d_tcounter, sizeof(int)));
     PN_TRY(hipStreamSynchronize(stream));
     cleanup();
 #undef PN_TRY
     tile_panels = panels;
     tile_bits = bits;
+    tile_rowbits = RB;
     tile_npieces = (int)pieces.size();
     tile_nsplit = (int)splits.size();
     tile_nslots = slots;
     return 0;
+}
+
+// Regroup the device CRS for the tiled SpMV.  tile_panels > 0 afterwards when the form was built; 0
+// when the matrix does not qualify (too many entries for 32-bit positions, or a key wider than 32
+// bits).  Non-zero return on errors.
+int Engine::build_panels(int bits) {
+    free_panels();
+    if (bits > 24) bits = 24;
+    if (nnz == 0 || nnz >= ((int64_t)1 << 32) - 1024) return 0;
+    // The weights of the 4096-row blocks decide the schedule: about equal (the fullest within 1.25 of
+    // the mean) and enough of them to go round -> whole blocks in step; else pieces drawn from a counter.
+    const int64_t nb12 = (n + 4095) >> 12;
+    bool even = false;
+    try {
+        std::vector<int64_t> head(nb12 + 1);
+        const size_t esz = rp64 ? 8 : 4;
+        std::vector<unsigned char> raw((size_t)(nb12 + 1) * esz);
+        hipError_t st = hipSuccess;
+        if (nb12 > 0)
+            st = hipMemcpy2DAsync(raw.data(), esz, d_rp, 4096 * esz, esz, (size_t)nb12, hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess)
+            st = hipMemcpyAsync(raw.data() + (size_t)nb12 * esz, (const unsigned char *)d_rp + (size_t)n * esz, esz,
+                                hipMemcpyDeviceToHost, stream);
+        if (st == hipSuccess) st = hipStreamSynchronize(stream);
+        if (st != hipSuccess) return fail("lanczos_hip: reading the row offsets failed: %s", hipGetErrorString(st));
+        for (int64_t K = 0; K <= nb12; ++K)
+            head[K] = rp64 ? ((const int64_t *)raw.data())[K] : (int64_t)((const int32_t *)raw.data())[K];
+        int64_t most = 0;
+        for (int64_t K = 0; K < nb12; ++K) most = std::max(most, head[K + 1] - head[K]);
+        even = nb12 >= kGroups(12) / 4 && 4 * most <= 5 * (nnz / nb12) + 8 * 256;
+    } catch (const std::bad_alloc &) {
+        return fail("lanczos_hip_create: out of host memory while planning the tiled SpMV");
+    }
+    if (const char *force = getenv("LANCZOS_HIP_TILE_EVEN")) even = atoi(force) != 0;   // for tests
+    if (even) return build_panels_shape<12, 256>(bits, true);
+    int rb = 8.0 * (double)n_ext > 256.0 * 1048576.0 ? 14 : 13;
+    if (const char *s = getenv("LANCZOS_HIP_TILE_ROWBITS"))
+        if (atoi(s) >= 12 && atoi(s) <= 14) rb = atoi(s);
+    if (rb == 12) return build_panels_shape<12, 256>(bits, false);
+    if (rb == 13) return build_panels_shape<13, 512>(bits, false);
+    return build_panels_shape<14, 1024>(bits, false);
 }
 
 int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts) {
@@ -588,30 +642,43 @@ int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, i
     n, p0, tile_npieces, draw, (const TilePiece *)d_tpieces, (const uint32_t *)d_tblock_ptr, (const uint16_t *)d_trow,  \
         (const uint32_t *)d_tcol, (const uint32_t *)d_tbase, (const double *)d_pval, x, xdot, y, d_tside, d_tdots,      \
         d_tcounter
+    const int groups = kGroups(tile_rowbits);
     if (tile_even) {
-        // equal work in every piece: launches of kGroups workgroups that start together and sweep the
+        // equal work in every piece: launches of `groups` workgroups that start together and sweep the
         // panels in step, so that an XCD's L2 holds one panel's slice of x at a time (one launch whose
         // workgroups draw the pieces as they finish loses that: 15.4 against 9.3 ms at 50M rows)
-        for (int p0 = 0; p0 < tile_npieces; p0 += kGroups) {
-            const dim3 grid(std::min(kGroups, tile_npieces - p0));
+        for (int p0 = 0; p0 < tile_npieces; p0 += groups) {
+            const dim3 grid(std::min(groups, tile_npieces - p0));
             if (tile_packed)
-                hipLaunchKernelGGL((k_spmv_tiles<false, true>), grid, dim3(kBlock), 0, stream, TILES_ARGS(p0, 0));
+                hipLaunchKernelGGL((k_spmv_tiles<false, true, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(p0, 0));
             else
-                hipLaunchKernelGGL((k_spmv_tiles<false, false>), grid, dim3(kBlock), 0, stream, TILES_ARGS(p0, 0));
+                hipLaunchKernelGGL((k_spmv_tiles<false, false, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(p0, 0));
         }
     } else {
         // uneven pieces, fullest blocks first: one launch whose workgroups draw pieces as they finish
         if (hipMemsetAsync(d_tcounter, 0, sizeof(int), stream) != hipSuccess)
             return fail("lanczos_hip: clearing the tiled SpMV's piece counter failed");
-        hipLaunchKernelGGL((k_spmv_tiles<true, false>), dim3(std::min(kGroups, tile_npieces)), dim3(kBlock), 0, stream,
-                           TILES_ARGS(0, 1));
+        const dim3 grid(std::min(groups, tile_npieces));
+        if (tile_rowbits == 12)
+            hipLaunchKernelGGL((k_spmv_tiles<true, false, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(0, 1));
+        else if (tile_rowbits == 13)
+            hipLaunchKernelGGL((k_spmv_tiles<true, false, 13, 512>), grid, dim3(512), 0, stream, TILES_ARGS(0, 1));
+        else
+            hipLaunchKernelGGL((k_spmv_tiles<true, false, 14, 1024>), grid, dim3(1024), 0, stream, TILES_ARGS(0, 1));
     }
 #undef TILES_ARGS
     int count = tile_npieces;
     if (tile_nsplit > 0) {
-        hipLaunchKernelGGL(k_tiles_combine, dim3(tile_nsplit * kCombineParts), dim3(kBlock), 0, stream, n,
-                           (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces);
-        count += tile_nsplit * kCombineParts;
+        const int parts = (1 << tile_rowbits) / kBlock;
+#define COMBINE_ARGS n, (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces
+        if (tile_rowbits == 12)
+            hipLaunchKernelGGL(k_tiles_combine<12>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);
+        else if (tile_rowbits == 13)
+            hipLaunchKernelGGL(k_tiles_combine<13>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);
+        else
+            hipLaunchKernelGGL(k_tiles_combine<14>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);
+#undef COMBINE_ARGS
+        count += tile_nsplit * parts;
     }
     if (tile_nfar > 0) {
         const int groups = (tile_nfar + kBlock - 1) / kBlock;

@@ -13,9 +13,10 @@ sys.path.insert(0, ".")
 import lanczos_amd as la
 
 CASES, SEED0 = 120, 0
-# "panel/even" and "panel/drawn": the tiled form with its schedule forced (whole row blocks launched in step on
-# the packed stream / pieces drawn from a counter on the unpacked one), whatever the row blocks weigh
-KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "panel/even", "panel/drawn", "dict"]
+# "panel/even" and "panel/drawnNN": the tiled form with its schedule forced (whole row blocks launched in step on
+# the packed stream / pieces of 2^NN-row blocks drawn from a counter on the unpacked one), whatever the blocks weigh
+KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "panel/even", "panel/drawn12",
+         "panel/drawn13", "panel/drawn14", "dict"]
 EPS = np.finfo(float).eps
 
 
@@ -80,8 +81,11 @@ def main():
         tol = (maxlen + 4) * EPS * (mabs @ np.abs(x)) + 1e-300
         for kind in KINDS:
             os.environ.pop("LANCZOS_HIP_TILE_EVEN", None)
+            os.environ.pop("LANCZOS_HIP_TILE_ROWBITS", None)
             if "/" in kind:
                 os.environ["LANCZOS_HIP_TILE_EVEN"] = "1" if kind.endswith("even") else "0"
+                if "drawn" in kind:
+                    os.environ["LANCZOS_HIP_TILE_ROWBITS"] = kind[-2:]
             try:
                 e = la.Engine(a, 3, spmv=kind.split("/")[0])
             except la.LanczosHipError as ex:

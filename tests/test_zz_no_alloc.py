@@ -68,10 +68,10 @@ def test_noalloc_rejects_what_the_scratch_cannot_hold(gpu):
             e.spmv_noalloc(xd.data_ptr(), yd.data_ptr(), None)
         with pytest.raises(la.LanczosHipError, match="NULL"):
             e.spmv_noalloc(None, yd.data_ptr(), None)
-    # tiled form: at most 64 pieces of split row blocks fit the scratch
+    # tiled form: the sums of at most 32 pieces of split 8192-row blocks fit the scratch
     g = crs_from_scipy(rmat_laplacian(16))
     with la.Engine(g, 3, spmv="panel") as e:
         xd = torch.ones(g.dimension, dtype=torch.float64, device="cuda")
         yd = torch.zeros(g.dimension, dtype=torch.float64, device="cuda")
-        with pytest.raises(la.LanczosHipError, match="takes at most 64"):
+        with pytest.raises(la.LanczosHipError, match="takes at most 32"):
             e.spmv_noalloc(xd.data_ptr(), yd.data_ptr(), None)
