@@ -105,8 +105,8 @@ typedef struct crs {
  *                          with wildly uneven rows)
  *   LANCZOS_HIP_TILE_EVEN  1 / 0 forces the tiled SpMV's schedule for even / uneven row blocks (tests; by
  *                          default the row blocks' weights decide)
- *   LANCZOS_HIP_TILE_ROWBITS 12, 13 or 14: rows per block of the uneven schedule as a power of two (default 13,
- *                          14 when the vector exceeds 256 MiB)
+ *   LANCZOS_HIP_TILE_ROWBITS 11 to 14: rows per block of the tiled SpMV as a power of two (default: even
+ *                          schedule 12, 11 for vectors up to 128 MiB; uneven 13, 14 beyond 256 MiB)
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up found (chunks, entries kept out of the
  *                          packed stream) on stderr
  */

@@ -33,20 +33,22 @@ namespace lz {
 
 static constexpr int kBlock = 256;              // threads of the small kernels (keys, bounds, combine, far, fold)
 static constexpr int kPieceEntries = 131072;    // entries in one piece at most (four times as many with 16384-row blocks)
-// Three shapes of a workgroup's row block, RB = log2(rows), T = threads = entries per chunk; the y block is
+// Four shapes of a workgroup's row block, RB = log2(rows), T = threads = entries per chunk; the y block is
 // 8 << RB bytes of LDS, and kGroups(RB) workgroups (16 wavefronts per CU) are resident together:
-//   RB 12, T  256   32 KiB, 4 per CU   even blocks (the packed word has 12 bits for the row)
+//   RB 11, T  128   16 KiB, 8 per CU   even blocks, x up to 128 MiB
+//   RB 12, T  256   32 KiB, 4 per CU   even blocks
 //   RB 13, T  512   64 KiB, 2 per CU   uneven blocks
 //   RB 14, T 1024  128 KiB, 1 per CU   uneven blocks, x beyond the memory-side cache (256 MiB)
 // Taller blocks put more of a block's entries into each panel, so more gathers share a sector: on R-MAT
 // graphs 8192 rows are worth 10 % at 2^24 rows and 16384 rows 20 % at 2^26, where the tiled SpMV is bound
-// by the sectors its misses move; on even matrices they change nothing (LDS holds as many rows either way).
-static constexpr int kGroups(int rb) { return 1024 >> (rb - 12); }
+// by the sectors its misses move; on even matrices, swept in step, they cost 6-30 %.
+static constexpr int kGroups(int rb) { return rb >= 12 ? 1024 >> (rb - 12) : 1024 << (12 - rb); }
 
 // slot < 0: the piece is its whole block and writes y; else it writes sums to side-buffer slot `slot`
 struct TilePiece { int32_t block; uint32_t chunk0; int32_t chunks; int32_t slot; uint32_t gchunk0; uint32_t unused; };
-static constexpr int kColField = 20;            // packed form: bits that hold the column relative to the chunk's first
-static constexpr uint32_t kFarColumn = (1u << kColField) - 1u;   // in the column field: no entry here (it is in the far list)
+// packed form: 32 - RB bits hold the column relative to the chunk's first; all ones there: no entry here (it is in the far list)
+static constexpr int col_field(int rb) { return 32 - rb; }
+static constexpr uint32_t far_column(int rb) { return (1u << (32 - rb)) - 1u; }
 static constexpr uint32_t kFarCap = 1u << 22;   // entries the far list holds at most
 struct TileSplit { int32_t block; int32_t slot0; int32_t count; int32_t unused; };
 
@@ -83,9 +85,9 @@ k_block_bounds(int64_t nnz, const uint32_t *__restrict__ keys, int64_t nblocks, 
 // One workgroup per chunk: the chunk's entries (positions of the (block, panel) order) sorted by
 // row in block, stable, and written out as the stream the product reads.  chunk_first[K] = number
 // of chunks of the blocks before K.  kPacked: one 32-bit word per entry, row in block << 20 | column -
-// base[chunk] with base the chunk's smallest column.  An entry 2^20 - 1 or more columns away from it
+// base[chunk] with base the chunk's smallest column.  An entry 2^(32 - RB) - 1 or more columns away from it
 // does not fit: its number goes to the far list (*far_count counts them, also beyond far_cap), and
-// its place in the stream, after the chunk's other entries, holds kFarColumn, which the product skips.
+// its place in the stream, after the chunk's other entries, holds far_column(RB), which the product skips.
 template <bool kPacked, int RB, int T>
 __global__ void __launch_bounds__(T)
 k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chunk_first,
@@ -122,7 +124,7 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
                 base[g] = cmin;
             }
             __syncthreads();
-            if (inside && c - lowest >= kFarColumn) {
+            if (inside && c - lowest >= far_column(RB)) {
                 const uint32_t slot = (uint32_t)atomicAdd(far_count, 1);
                 if (slot < far_cap) far_entry[slot] = e[0];
                 key[0] = (uint32_t)(1 << RB);      // sorts behind the entries that stay
@@ -132,10 +134,10 @@ k_tile_place(uint32_t chunks, int64_t nblocks, const uint32_t *__restrict__ chun
         Sort(tmp).Sort(key, e, 0, RB + 1);
         if (kPacked) {
             if (e[0] != 0xffffffffu) {
-                tcol[q] = (key[0] << kColField) | ((uint32_t)col[e[0]] - lowest);
+                tcol[q] = (key[0] << col_field(RB)) | ((uint32_t)col[e[0]] - lowest);
                 tval[q] = val[e[0]];
             } else if (inside) {                       // the stream positions are the same set before and after the sort
-                tcol[q] = kFarColumn;
+                tcol[q] = far_column(RB);
                 tval[q] = 0.0;
             }
         } else if (e[0] != 0xffffffffu) {
@@ -249,7 +251,7 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
                     vn = __builtin_nontemporal_load(tval + qn);
                 }
             } else if (kPacked) {
-                uint32_t pk = kFarColumn;
+                uint32_t pk = far_column(RB);
                 double v = 0.0;
                 if (q0 + tid < b) {
                     pk = __builtin_nontemporal_load(tcol + q0 + tid);
@@ -257,10 +259,10 @@ k_spmv_tiles(int64_t n, int piece0, int npieces, int draw, const TilePiece *__re
                 }
                 const uint32_t cb = cbn;           // uniform: one base per chunk, read one chunk ahead
                 if (q0 + T < b) cbn = tbase[pc.gchunk0 + (q0 - a) / T + 1];
-                const uint32_t rel = pk & kFarColumn;
-                const bool live = rel != kFarColumn;       // else: no entry, or one that k_tiles_far adds afterwards
+                const uint32_t rel = pk & far_column(RB);
+                const bool live = rel != far_column(RB);       // else: no entry, or one that k_tiles_far adds afterwards
                 const double xv = live ? x[(uint64_t)cb + rel] : 0.0;
-                r = live ? (int)(pk >> kColField) : -1;
+                r = live ? (int)(pk >> col_field(RB)) : -1;
                 sum = v * xv;                              // v on both sides of the test: its load stays up here too
             } else if (q0 + tid < b) {
                 const uint32_t c = __builtin_nontemporal_load(tcol + q0 + tid);
@@ -518,7 +520,7 @@ int Engine::build_panels_shape(int bits, bool even) {
     // when no chunk's columns span 2^20 or more.  Otherwise, and for uneven blocks whose chunks cross
     // many small tiles, 14 bytes: value, column, row.
     tile_packed = false;
-    if (RB == 12 && even && chunks > 0) {
+    if (even && chunks > 0) {
         int far = 0;
         uint32_t *far_raw = nullptr;                        // unsorted, as the workgroups append them
         PN_TRY(hipMalloc(&d_tbase, sizeof(uint32_t) * chunks));
@@ -628,13 +630,16 @@ int Engine::build_panels(int bits) {
         return fail("lanczos_hip_create: out of host memory while planning the tiled SpMV");
     }
     if (const char *force = getenv("LANCZOS_HIP_TILE_EVEN")) even = atoi(force) != 0;   // for tests
-    if (even) return build_panels_shape<12, 256>(bits, true);
-    int rb = 8.0 * (double)n_ext > 256.0 * 1048576.0 ? 14 : 13;
+    // even blocks: 4096 rows, 2048 while x is small against the memory-side cache (random 21 per row: 1.65
+    // against 1.74 ms at 10M rows, 9.86 against 9.33 at 50M; 8192 and 16384 rows: 1.84 / 10.0 and 2.32 / 11.1)
+    const double x_mib = 8.0 * (double)n_ext / 1048576.0;
+    int rb = even ? (x_mib <= 128.0 ? 11 : 12) : x_mib > 256.0 ? 14 : 13;
     if (const char *s = getenv("LANCZOS_HIP_TILE_ROWBITS"))
-        if (atoi(s) >= 12 && atoi(s) <= 14) rb = atoi(s);
-    if (rb == 12) return build_panels_shape<12, 256>(bits, false);
-    if (rb == 13) return build_panels_shape<13, 512>(bits, false);
-    return build_panels_shape<14, 1024>(bits, false);
+        if (atoi(s) >= 11 && atoi(s) <= 14) rb = atoi(s);
+    if (rb == 11) return build_panels_shape<11, 128>(bits, even);
+    if (rb == 12) return build_panels_shape<12, 256>(bits, even);
+    if (rb == 13) return build_panels_shape<13, 512>(bits, even);
+    return build_panels_shape<14, 1024>(bits, even);
 }
 
 int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, int *nparts) {
@@ -649,17 +654,30 @@ int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, i
         // workgroups draw the pieces as they finish loses that: 15.4 against 9.3 ms at 50M rows)
         for (int p0 = 0; p0 < tile_npieces; p0 += groups) {
             const dim3 grid(std::min(groups, tile_npieces - p0));
-            if (tile_packed)
-                hipLaunchKernelGGL((k_spmv_tiles<false, true, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(p0, 0));
-            else
-                hipLaunchKernelGGL((k_spmv_tiles<false, false, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(p0, 0));
+#define EVEN_LAUNCH(RB, T)                                                                                              \
+    if (tile_packed)                                                                                                     \
+        hipLaunchKernelGGL((k_spmv_tiles<false, true, RB, T>), grid, dim3(T), 0, stream, TILES_ARGS(p0, 0));             \
+    else                                                                                                                 \
+        hipLaunchKernelGGL((k_spmv_tiles<false, false, RB, T>), grid, dim3(T), 0, stream, TILES_ARGS(p0, 0))
+            if (tile_rowbits == 11) {
+                EVEN_LAUNCH(11, 128);
+            } else if (tile_rowbits == 12) {
+                EVEN_LAUNCH(12, 256);
+            } else if (tile_rowbits == 13) {
+                EVEN_LAUNCH(13, 512);
+            } else {
+                EVEN_LAUNCH(14, 1024);
+            }
+#undef EVEN_LAUNCH
         }
     } else {
         // uneven pieces, fullest blocks first: one launch whose workgroups draw pieces as they finish
         if (hipMemsetAsync(d_tcounter, 0, sizeof(int), stream) != hipSuccess)
             return fail("lanczos_hip: clearing the tiled SpMV's piece counter failed");
         const dim3 grid(std::min(groups, tile_npieces));
-        if (tile_rowbits == 12)
+        if (tile_rowbits == 11)
+            hipLaunchKernelGGL((k_spmv_tiles<true, false, 11, 128>), grid, dim3(128), 0, stream, TILES_ARGS(0, 1));
+        else if (tile_rowbits == 12)
             hipLaunchKernelGGL((k_spmv_tiles<true, false, 12, 256>), grid, dim3(256), 0, stream, TILES_ARGS(0, 1));
         else if (tile_rowbits == 13)
             hipLaunchKernelGGL((k_spmv_tiles<true, false, 13, 512>), grid, dim3(512), 0, stream, TILES_ARGS(0, 1));
@@ -671,7 +689,9 @@ int Engine::launch_spmv_panels(const double *x, const double *xdot, double *y, i
     if (tile_nsplit > 0) {
         const int parts = (1 << tile_rowbits) / kBlock;
 #define COMBINE_ARGS n, (const TileSplit *)d_tsplits, (const double *)d_tside, xdot, y, d_tdots + tile_npieces
-        if (tile_rowbits == 12)
+        if (tile_rowbits == 11)
+            hipLaunchKernelGGL(k_tiles_combine<11>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);
+        else if (tile_rowbits == 12)
             hipLaunchKernelGGL(k_tiles_combine<12>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);
         else if (tile_rowbits == 13)
             hipLaunchKernelGGL(k_tiles_combine<13>, dim3(tile_nsplit * parts), dim3(kBlock), 0, stream, COMBINE_ARGS);

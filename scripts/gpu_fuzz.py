@@ -15,7 +15,7 @@ import lanczos_amd as la
 CASES, SEED0 = 120, 0
 # "panel/even" and "panel/drawnNN": the tiled form with its schedule forced (whole row blocks launched in step on
 # the packed stream / pieces of 2^NN-row blocks drawn from a counter on the unpacked one), whatever the blocks weigh
-KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "panel/even", "panel/drawn12",
+KINDS = ["auto", "vector", "stream", "pipe", "pipe_nt", "merge", "rows", "panel", "panel/even", "panel/drawn11", "panel/drawn12",
          "panel/drawn13", "panel/drawn14", "dict"]
 EPS = np.finfo(float).eps
 
