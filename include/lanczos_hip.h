@@ -162,7 +162,7 @@ enum {
                                     matrices); needs every 64-row group to hold <= 481 entries */
     LANCZOS_HIP_SPMV_PANEL = 6,  /* for matrices whose rows reach all over a vector too large for the
                                     caches (random sparsity, large power-law graphs): entries regrouped on
-                                    the device by (block of 4096 rows, column panel of 2^16 or 2^10 columns);
+                                    the device by (block of 2048 to 16384 rows, column panel of 2^16 or 2^10 columns);
                                     a workgroup keeps its rows of y in LDS and sweeps the panels, whose slice
                                     of x stays in cache; row blocks too full for one workgroup are cut into
                                     pieces whose sums a second kernel adds in order.  Needs nnz < 2^32.
@@ -305,7 +305,7 @@ int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host
  * (per-workgroup partial sums; on the merge SpMV the rows shared between tiles; on the tiled SpMV
  * the sums of the pieces of split row blocks) is a fixed array of 3 178 496 bytes in the library's
  * device image, one copy per GPU, held until the process ends.  Limits: on the merge SpMV at most
- * 67 108 864 entries, on the tiled SpMV at most 64 pieces of split row blocks, otherwise none beyond
+ * 67 108 864 entries, on the tiled SpMV at most 262 144 rows of split-block pieces (32 pieces of 8192 rows), otherwise none beyond
  * the engine's own; beyond them the call fails with a message and launches nothing.  Calls on the same
  * GPU share the array: two that overlap in time (different streams or threads) race on it.
  */

@@ -2,23 +2,28 @@
 // large for the caches (random sparsity, power-law graphs: the row-wise product
 // of src/crs.c:155-178 then fetches one memory line per entry, and the fabric's
 // request rate, not its bandwidth, sets the time).  The entries are regrouped
-// once, on the device, by (row block, column panel): a row block is 4096 rows,
-// whose part of y a workgroup keeps in LDS; a panel is 2^bits columns, whose
-// slice of x fits an XCD's L2.  A block's entries form one stream, panel after
-// panel, cut into chunks of 256; inside a chunk the entries are sorted by row
-// (stable, so a row's entries keep their panel order).  A workgroup takes a
-// piece of at most 1024 chunks of one block: a chunk is multiplied lane per
-// entry, runs of equal rows are summed inside each wavefront (a segmented
-// shuffle scan) and the first lane of a run adds it to the row's LDS slot,
-// collecting the parts of a run that crosses wavefronts; chunks are separated
-// by barriers -- no atomics, the same sums on every run.  A block that fits one piece goes straight to y; the pieces of a
-// larger block (the hub rows of a power-law graph put 2 % of all entries into
-// one block) leave their 4096 sums in a side buffer, and a second kernel adds
-// them in piece order.  Workgroups of one launch start together; where the
-// blocks carry equal work they sweep the panels in step and the gathers hit
-// L2.  12 bytes per entry (value; row in block and column relative to the
-// chunk's first in one word) where no chunk's columns span 2^20, else 14:
-// value, column, row in block.
+// once, on the device, by (row block, column panel): a row block is 2048 to
+// 16384 rows, whose part of y a workgroup keeps in LDS; a panel is 2^bits
+// columns, whose slice of x stays in cache while it is used.  A block's entries
+// form one stream, panel after panel, cut into chunks of as many entries as the
+// workgroup has threads; inside a chunk the entries are sorted by row (stable,
+// so a row's entries keep their panel order).  A workgroup takes a piece -- a
+// whole block, or a share of a block too full for one workgroup: a chunk is
+// multiplied lane per entry, runs of equal rows are summed inside each
+// wavefront (a segmented shuffle scan) and the first lane of a run adds it to
+// the row's LDS slot, collecting the parts of a run that crosses wavefronts;
+// chunks are separated by barriers -- no atomics on data, the same sums on
+// every run.  A whole block goes straight to y; the pieces of a split block
+// (the hub rows of a power-law graph put 2 % of all entries into one block)
+// leave their sums in a side buffer, and a second kernel adds them in piece
+// order.  Two schedules.  Even blocks (random sparsity): launches of as many
+// workgroups as are resident together; they start together, carry equal work
+// per panel, sweep the panels in step, and the gathers hit L2; 12 bytes per
+// entry (value; row in block and column relative to the chunk's first in one
+// word, the rare entry too far from it kept in a list of its own).  Uneven
+// blocks (power-law graphs): one launch whose workgroups draw pieces from a
+// counter, fullest blocks first, with the stream read two chunks and the
+// gathers issued one chunk ahead; 14 bytes per entry (value, column, row).
 #include <hipcub/hipcub.hpp>
 
 #include <stdlib.h>
