@@ -1096,7 +1096,8 @@ k_row_stats(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ co
     for (int64_t t = (int64_t)blockIdx.x * kBlock + threadIdx.x; t * stride + 1 < n; t += step) {
         const int64_t r = t * stride;
         const RP a0 = rp[r], a1 = rp[r + 1], a2 = rp[r + 2];
-        const RP len = (a1 - a0) < (a2 - a1) ? (a1 - a0) : (a2 - a1);
+        RP len = (a1 - a0) < (a2 - a1) ? (a1 - a0) : (a2 - a1);
+        if (len > 4096) len = 4096;          // a sample is enough; hub rows would keep one thread busy for milliseconds
         for (RP j = 0; j < len; ++j) {
             pairs++;
             alike += (col[a1 + j] == col[a0 + j] + 1);

@@ -57,17 +57,44 @@ static constexpr uint32_t far_column(int rb) { return (1u << (32 - rb)) - 1u; }
 static constexpr uint32_t kFarCap = 1u << 22;   // entries the far list holds at most
 struct TileSplit { int32_t block; int32_t slot0; int32_t count; int32_t unused; };
 
+// keys[e] = (row block << jbits) | panel, idx[e] = e, rowid[e] = row, for every entry e.  A thread per
+// row; rows of more than kKeyRowMax entries are left to k_tile_keys_long (their numbers go to `longs`,
+// *nlong counts them): the hub rows of a power-law graph hold 10^5 to 10^6 entries.
+static constexpr int kKeyRowMax = 256;
 template <typename RP>
 __global__ void __launch_bounds__(kBlock)
 k_tile_keys(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col, int rowbits, int bits, int jbits,
-            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx, int32_t *__restrict__ rowid) {
+            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx, int32_t *__restrict__ rowid,
+            int32_t *__restrict__ longs, int *__restrict__ nlong) {
     const int64_t step = (int64_t)gridDim.x * kBlock;
-    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step)
-        for (int64_t e = (int64_t)rp[r]; e < (int64_t)rp[r + 1]; ++e) {
+    for (int64_t r = (int64_t)blockIdx.x * kBlock + threadIdx.x; r < n; r += step) {
+        const int64_t e0 = (int64_t)rp[r], e1 = (int64_t)rp[r + 1];
+        if (e1 - e0 > kKeyRowMax) {
+            longs[atomicAdd(nlong, 1)] = (int32_t)r;
+            continue;
+        }
+        for (int64_t e = e0; e < e1; ++e) {
             keys[e] = ((uint32_t)(r >> rowbits) << jbits) | ((uint32_t)col[e] >> bits);
             idx[e] = (uint32_t)e;
             rowid[e] = (int32_t)r;
         }
+    }
+}
+
+// one workgroup per long row
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_tile_keys_long(const int32_t *__restrict__ longs, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+                 int rowbits, int bits, int jbits, uint32_t *__restrict__ keys, uint32_t *__restrict__ idx,
+                 int32_t *__restrict__ rowid) {
+    const int32_t r = longs[blockIdx.x];
+    const int64_t e1 = (int64_t)rp[r + 1];
+    const uint32_t high = (uint32_t)(r >> rowbits) << jbits;
+    for (int64_t e = (int64_t)rp[r] + threadIdx.x; e < e1; e += kBlock) {
+        keys[e] = high | ((uint32_t)col[e] >> bits);
+        idx[e] = (uint32_t)e;
+        rowid[e] = r;
+    }
 }
 
 // block_ptr[K] = first position of the sorted keys that belongs to row block K or a later one, K = 0..nblocks
@@ -451,14 +478,38 @@ int Engine::build_panels_shape(int bits, bool even) {
         PN_TRY(hipMalloc(&d_idx[b], sizeof(uint32_t) * nnz));
     }
     PN_TRY(hipMalloc(&d_rowid, sizeof(int32_t) * nnz));
+    // d_keys[1] is free until the sort: its head holds the list of long rows (at most nnz / 257 of them) and
+    // their count behind it
+    int32_t *d_longs = (int32_t *)d_keys[1];
+    const int64_t long_cap = nnz / (kKeyRowMax + 1) + 1;
+    int nlong = 0;
+    if ((long_cap + 1) * (int64_t)sizeof(int32_t) > (int64_t)sizeof(uint32_t) * nnz) {   // a handful of entries: no room, no need
+        (void)hipFree(d_keys[1]);
+        d_keys[1] = nullptr;
+        PN_TRY(hipMalloc(&d_keys[1], sizeof(uint32_t) * (size_t)std::max<int64_t>(nnz, long_cap + 1)));
+        d_longs = (int32_t *)d_keys[1];
+    }
+    int *d_nlong = (int *)(d_longs + long_cap);
+    PN_TRY(hipMemsetAsync(d_nlong, 0, sizeof(int), stream));
     const int rblocks = (int)std::min<int64_t>(max_blocks, (n + kBlock - 1) / kBlock);
     if (rp64)
         hipLaunchKernelGGL((k_tile_keys<int64_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int64_t *)d_rp,
-                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid, d_longs, d_nlong);
     else
         hipLaunchKernelGGL((k_tile_keys<int32_t>), dim3(rblocks), dim3(kBlock), 0, stream, n, (const int32_t *)d_rp,
-                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+                           (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid, d_longs, d_nlong);
     PN_TRY(hipGetLastError());
+    PN_TRY(hipMemcpyAsync(&nlong, d_nlong, sizeof(int), hipMemcpyDeviceToHost, stream));
+    PN_TRY(hipStreamSynchronize(stream));
+    if (nlong > 0) {
+        if (rp64)
+            hipLaunchKernelGGL((k_tile_keys_long<int64_t>), dim3(nlong), dim3(kBlock), 0, stream, (const int32_t *)d_longs,
+                               (const int64_t *)d_rp, (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+        else
+            hipLaunchKernelGGL((k_tile_keys_long<int32_t>), dim3(nlong), dim3(kBlock), 0, stream, (const int32_t *)d_longs,
+                               (const int32_t *)d_rp, (const int32_t *)d_col, RB, bits, jbits, d_keys[0], d_idx[0], d_rowid);
+        PN_TRY(hipGetLastError());
+    }
     hipcub::DoubleBuffer<uint32_t> keys(d_keys[0], d_keys[1]);
     hipcub::DoubleBuffer<uint32_t> vals(d_idx[0], d_idx[1]);
     size_t tmp_bytes = 0;
