@@ -107,8 +107,8 @@ typedef struct crs {
  *                          default the row blocks' weights decide)
  *   LANCZOS_HIP_TILE_ROWBITS 11 to 14: rows per block of the tiled SpMV as a power of two (default: even
  *                          schedule 12, 11 for vectors up to 128 MiB; uneven 13, 14 beyond 256 MiB)
- *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up found (chunks, entries kept out of the
- *                          packed stream) on stderr
+ *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up chose (schedule, block shape, pieces,
+ *                          entries kept out of the packed stream) on stderr
  */
 int lanczos_hip_crs(const Mat_Crs *mat, double eigenvalues[], double *eigenvectors[],
                     int nth_eig, int max_iter, double threshold);

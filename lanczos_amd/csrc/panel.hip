@@ -645,6 +645,11 @@ int Engine::build_panels_shape(int bits, bool even) {
     PN_TRY(hipStreamSynchronize(stream));
     cleanup();
 #undef PN_TRY
+    if (getenv("LANCZOS_HIP_VERBOSE"))
+        fprintf(stderr, "lanczos_hip: tiled SpMV, %s schedule, %d-row blocks, %d threads, panels of 2^%d columns, %zu pieces, "
+                        "%zu split blocks (%d side slots), %s stream\n",
+                even ? "even" : "uneven", kRows, T, bits, pieces.size(), splits.size(), slots,
+                tile_packed ? "12-byte" : "14-byte");
     tile_panels = panels;
     tile_bits = bits;
     tile_rowbits = RB;
