@@ -529,8 +529,14 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, do
         // 0.363 ms against 0.370 ms with eight workgroups per CU on the 256^3 Laplacian)
         int blocks = (int)std::min<int64_t>(e->cus * 2 / 8 * 8, round_up(chunks, 8));
         *nparts = blocks;
-        hipLaunchKernelGGL((k_spmv_rows<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp, e->d_col,
-                           e->d_val, x, xdot, y, parts);
+        // LANCZOS_HIP_ROWS_MASK=0: the tile loads without the descriptors that end at the group's last entry
+        static const bool mask = !(getenv("LANCZOS_HIP_ROWS_MASK") && atoi(getenv("LANCZOS_HIP_ROWS_MASK")) == 0);
+        if (mask)
+            hipLaunchKernelGGL((k_spmv_rows<RP, true>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp,
+                               e->d_col, e->d_val, x, xdot, y, parts);
+        else
+            hipLaunchKernelGGL((k_spmv_rows<RP, false>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp,
+                               e->d_col, e->d_val, x, xdot, y, parts);
         return;
     }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_PIPE || e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {

@@ -20,6 +20,7 @@ constexpr int kWavesPerBlock = 4;
 // it (7.0 vs 6.2 TB/s measured on k_dots) because it does not churn L2/MALL.
 typedef double d2v __attribute__((ext_vector_type(2)));
 typedef int i4v __attribute__((ext_vector_type(4)));
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ double2 ld_stream(const double2 *p) {
     const d2v t = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(p));
     return make_double2(t.x, t.y);
@@ -33,6 +34,18 @@ __device__ __forceinline__ void st_stream(double2 *p, const double2 &v) {
     t.x = v.x;
     t.y = v.y;
     __builtin_nontemporal_store(t, reinterpret_cast<d2v *>(p));
+}
+
+// Lane L's value as a wave-uniform (scalar-register) value
+template <int L>
+__device__ __forceinline__ int32_t uniform_lane(int32_t v) {
+    return __builtin_amdgcn_readlane(v, L);
+}
+template <int L>
+__device__ __forceinline__ int64_t uniform_lane(int64_t v) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, L);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)((uint64_t)v >> 32), L);
+    return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
 // ---------------------------------------------------------------------------
@@ -569,7 +582,7 @@ constexpr int kRowChunk = 8;
 constexpr int kRowsAlignC = 32, kRowsAlignV = 16;  // entries per 128-byte line of col / val
 constexpr int kRowsMaxSpan = kTile - (kRowsAlignC - 1);
 
-template <typename RP>
+template <typename RP, bool MASK>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__restrict__ col,
             const double *__restrict__ val, const double *__restrict__ x,
@@ -610,19 +623,47 @@ k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__
     // hint: the entries are read once per product and should not push x out of the caches (3 % on
     // the 256^3 Laplacian).  Granules past the end of the arrays are clamped to the last one; no row
     // reads those tile slots.
-    auto issue_colval = [&](RP s_lo, i4v (&cj)[2], d2v (&vj)[4]) {
-        const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
+    // MASK: the tiles are loaded through buffer descriptors that end at the group's last entry (rounded up to
+    // the 16-byte granule), so lanes past it return zeros without a memory request -- those lines belong to
+    // the next group's tile, which the neighbouring wavefront of this workgroup requests anyway.  The
+    // descriptor is rebuilt per group from wave-uniform values (scalar registers); its base moves with the
+    // group, so arrays beyond 4 GiB are addressed as well.
+    auto issue_colval = [&](RP lo_lane, RP hi_lane, i4v (&cj)[2], d2v (&vj)[4]) {
+        if (MASK) {
+            const RP s_lo = uniform_lane<0>(lo_lane), s_hi = uniform_lane<63>(hi_lane);
+            const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
+            RP ec = (s_hi - ac + 3) & ~(RP)3, ev = (s_hi - av + 1) & ~(RP)1;
+            ec = ec < (RP)kTile ? ec : (RP)kTile;
+            ev = ev < (RP)kTile ? ev : (RP)kTile;
+            const __amdgpu_buffer_rsrc_t rc =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(col + ac), 0, (int)ec * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rv =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(val + av), 0, (int)ev * 8, 0x00020000);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            RP j = ac + u * 256 + 4 * lane;
-            j = j < last4 ? j : last4;
-            cj[u] = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(col + j));
-        }
+            for (int u = 0; u < 2; ++u) {
+                const u4v t = __builtin_amdgcn_raw_buffer_load_b128(rc, u * 1024 + 16 * lane, 0, 2);
+                cj[u] = i4v{(int)t.x, (int)t.y, (int)t.z, (int)t.w};
+            }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            RP j = av + u * 128 + 2 * lane;
-            j = j < last2 ? j : last2;
-            vj[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + j));
+            for (int u = 0; u < 4; ++u) {
+                const u4v t = __builtin_amdgcn_raw_buffer_load_b128(rv, u * 1024 + 16 * lane, 0, 2);
+                vj[u] = __builtin_bit_cast(d2v, t);
+            }
+        } else {
+            const RP s_lo = __shfl(lo_lane, 0);
+            const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                RP j = ac + u * 256 + 4 * lane;
+                j = j < last4 ? j : last4;
+                cj[u] = __builtin_nontemporal_load(reinterpret_cast<const i4v *>(col + j));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                RP j = av + u * 128 + 2 * lane;
+                j = j < last2 ? j : last2;
+                vj[u] = __builtin_nontemporal_load(reinterpret_cast<const d2v *>(val + j));
+            }
         }
     };
     auto step = [&](int64_t i, i4v (&c_c)[2], d2v (&v_c)[4], i4v (&c_n)[2], d2v (&v_n)[4], RP &lo_c,
@@ -651,7 +692,7 @@ k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__
         const double xd = xdot[row < n ? row : n - 1];
         // (c) offsets of group i+2, col/val of group i+1 (behind the gathers in the queue)
         offsets(row_of(i + 2 < count ? i + 2 : count - 1), lo_c, hi_c);
-        issue_colval(__shfl(lo_n, 0), c_n, v_n);
+        issue_colval(lo_n, hi_n, c_n, v_n);
         // (d) the row sum, left to right
         double sum = 0.0;
 #pragma unroll
@@ -688,7 +729,7 @@ k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__
         offsets(row_of(count > 1 ? 1 : 0), loB, hiB);
         i4v cA[2], cB[2];
         d2v vA[4], vB[4];
-        issue_colval(__shfl(loA, 0), cA, vA);
+        issue_colval(loA, hiA, cA, vA);
         int64_t i = 0;
         for (; i + 1 < count; i += 2) {
             step(i, cA, vA, cB, vB, loA, hiA, loB, hiB);
