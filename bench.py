@@ -300,7 +300,7 @@ def roofline_from_profile(prof: dict) -> dict:
     }
 
 
-def single_gpu(args) -> dict:
+def single_gpu(args, keeper=None) -> dict:
     import torch
     import lanczos_amd as la
 
@@ -417,8 +417,25 @@ def single_gpu(args) -> dict:
         "ritz_lowest4": [float(x) for x in ritz],
         "setup_s": {"generate": t_gen, "upload": t_upload},
     }
+    out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, args.reorth,
+                                                  out["roofline"]["algorithmic_bytes_per_launch"])
+    if keeper is not None:
+        keeper.publish(out)           # the primary figure stands from here on
+
+    def section(name, fn):
+        """A secondary section: an error is recorded in the line instead of ending the run."""
+        try:
+            fn()
+        except Exception as exc:  # noqa: BLE001
+            out.setdefault("section_errors", {})[name] = f"{type(exc).__name__}: {exc}"[:300]
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+        if keeper is not None:
+            keeper.publish(out)
+
     # the same K steps with the orthogonality tracker deciding when to reorthogonalise
-    if args.reorth == "full" and not args.main_only:
+    def sec_selective():
         with la.Engine(a, K + 1, reorth="selective", spmv=args.spmv) as es:
             es.set_start(v0)
             es.run(min(W, K))
@@ -437,7 +454,7 @@ def single_gpu(args) -> dict:
             }
     # the configuration the metric is quoted on is 300 steps; when the caller asked for another count the
     # full-length run is reported beside it (the cost of a step grows with its index)
-    if K != 300 and args.workload == "lap256" and not args.main_only:
+    def sec_300():
         with la.Engine(a, 301, reorth=args.reorth, spmv=args.spmv, profile=True) as ef:
             ef.set_start(v0)
             ef.run(min(W, 5))
@@ -454,8 +471,9 @@ def single_gpu(args) -> dict:
                 "steps": 300, "value": 300 / dtf, "unit": "iters/s", "ms_per_step": dtf / 300 * 1e3, "roofline": rf,
                 "ritz_lowest4": [float(x) for x in la.ritz_values(af, bf, 300, 4)],
             }
+
     # time to solution: selective reorthogonalisation until the lowest eigenvalue stands (closed form known)
-    if args.converge_steps > 0 and d == 3:
+    def sec_converge():
         S = args.converge_steps
         one = 2.0 - 2.0 * np.cos(np.pi / (N + 1))
         exact = 3.0 * one
@@ -474,15 +492,8 @@ def single_gpu(args) -> dict:
                 "lowest_ritz": lowest, "lowest_exact": exact, "rel_err": abs(lowest - exact) / exact,
                 "basis_GB": (S + 1) * 8.0 * n / 1e9,
             }
-    out["roofline"]["traffic"] = measured_traffic(out["roofline"]["kernel"], args.workload, args.reorth,
-                                                  out["roofline"]["algorithmic_bytes_per_launch"])
-    if not args.no_block:
-        out["block_variant"] = block_variant(la, a)
-    if args.rand_rows > 0:
-        out["random_symmetric"] = random_symmetric_section(la, torch, args.rand_rows)
-    if args.rmat_scale > 0:
-        out["power_law_graph"] = power_law_section(la, torch, args.rmat_scale)
-    if not args.no_cpu_baseline:
+
+    def sec_cpu():
         cb = cpu_baseline(a, v0, args.cpu_steps)
         s = min(cb["steps"], K)
         # GPU rate over the same first s iterations (its cost per step also grows with k)
@@ -501,10 +512,68 @@ def single_gpu(args) -> dict:
         }
         del cb["alpha"], cb["beta"], cb["ritz"]
         out["cpu_baseline"] = cb
+
+    # the CPU leg first: the line the round driver reads must carry it whatever the later sections do
+    if not args.no_cpu_baseline:
+        section("cpu_baseline", sec_cpu)
+    if args.reorth == "full" and not args.main_only:
+        section("selective_reorth", sec_selective)
+    if K != 300 and args.workload == "lap256" and not args.main_only:
+        section("config_300_steps", sec_300)
+    if args.converge_steps > 0 and d == 3:
+        section("converged_run", sec_converge)
+    if not args.no_block:
+        section("block_variant", lambda: out.__setitem__("block_variant", block_variant(la, a)))
+    if args.rand_rows > 0:
+        section("random_symmetric",
+                lambda: out.__setitem__("random_symmetric", random_symmetric_section(la, torch, args.rand_rows)))
+    if args.rmat_scale > 0:
+        section("power_law_graph",
+                lambda: out.__setitem__("power_law_graph", power_law_section(la, torch, args.rmat_scale)))
     if args.big_grid > 0:
-        del a
-        out["strong_scaling_laplacian"] = big_laplacian_section(la, torch, args.big_grid)
+        def sec_big():
+            nonlocal a
+            a = None                  # the 256^3 host arrays go before the 512^3 ones are generated
+            out["strong_scaling_laplacian"] = big_laplacian_section(la, torch, args.big_grid)
+        section("strong_scaling_laplacian", sec_big)
     return out
+
+
+class LineKeeper:
+    """Holds the result line outside this process.  A child forked before anything touches the GPU
+    reads what `publish` sends and, when this process ends -- by returning, by an exception or by an
+    abort inside a library -- writes the last complete line to the real stdout.  The primary figure is
+    published as soon as it is measured, so a failure in a later section cannot take it away."""
+
+    def __init__(self, out_fd: int):
+        r, w = os.pipe()
+        self.pid = os.fork()
+        if self.pid == 0:
+            os.close(w)
+            buf = b""
+            while True:
+                chunk = os.read(r, 1 << 16)
+                if not chunk:
+                    break
+                buf += chunk
+                cut = buf.rfind(b"\n", 0, len(buf) - 1)      # keep the last complete line and what follows it
+                if cut >= 0 and buf.endswith(b"\n"):
+                    buf = buf[cut + 1:]
+            lines = [ln for ln in buf.split(b"\n") if ln.strip()]
+            if buf.endswith(b"\n") and lines:
+                os.write(out_fd, lines[-1] + b"\n")
+            elif len(lines) > 1:
+                os.write(out_fd, lines[-2] + b"\n")
+            os._exit(0)
+        os.close(r)
+        self.w = w
+
+    def publish(self, obj: dict):
+        os.write(self.w, (json.dumps(obj) + "\n").encode())
+
+    def close(self):
+        os.close(self.w)
+        os.waitpid(self.pid, 0)
 
 
 def launch_command(argv, gpus: int, port: int) -> list:
@@ -551,16 +620,20 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1 or args.force_dist:
-        from lanczos_amd.dist import bench_distributed
-        out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS, json_fd)
-    else:
-        out = single_gpu(args)
-    sys.stdout.flush()
-    if out is not None:
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    keeper = LineKeeper(json_fd)          # forks: before torch is imported or the GPU touched
     os.close(json_fd)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    try:
+        if args.gpus > 1 or world > 1 or args.force_dist:
+            from lanczos_amd.dist import bench_distributed
+            out = bench_distributed(args, WORKLOADS, algorithmic_bytes, HBM_PEAK_GBPS, keeper)
+        else:
+            out = single_gpu(args, keeper)
+        sys.stdout.flush()
+        if out is not None:
+            keeper.publish(out)
+    finally:
+        keeper.close()
 
 
 if __name__ == "__main__":

@@ -515,7 +515,7 @@ def _timed_dist_run(torch, dist, runner, v0, steps, warm):
     return float(t.item())
 
 
-def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None):
+def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None):
     """bench.py for --gpus N > 1 (launched by torch.distributed.run, one rank per GPU)."""
     import torch
     import torch.distributed as dist
@@ -598,23 +598,28 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None
             "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
             "ritz_lowest4": [float(x) for x in ritz],
         }
-    # The primary figure stands from here on.  What follows are secondary sections; should one of them
-    # hang on some rank (they have never run on more than one GPU), every rank leaves after a deadline and
-    # rank 0 prints the line as it stands, so the run still reports its metric.
-    import json
-    import sys
+    # The primary figure stands from here on: rank 0 hands the line to its keeper (a process of its own that
+    # prints the last line it was given when this one ends, however it ends).  What follows are secondary
+    # sections; should one of them hang on some rank (they have never run on more than one GPU), every rank
+    # leaves after a deadline, so the run still reports its metric.
     import threading
     state = {"done": False}
+
+    def publish():
+        if rank == 0 and out is not None and keeper is not None:
+            keeper.publish(out)
+
+    publish()
 
     def _bail():
         if state["done"]:
             return
         if rank == 0 and out is not None:
             out["secondary_sections"] = "abandoned at the deadline"
-            os.write(json_fd if json_fd is not None else 1, (json.dumps(out) + "\n").encode())
+            publish()
         os._exit(0)
 
-    deadline = float(os.environ.get("LANCZOS_BENCH_SECONDARY_DEADLINE_S", "900"))
+    deadline = float(os.environ.get("LANCZOS_BENCH_SECONDARY_DEADLINE_S", "420"))
     timer = threading.Timer(deadline, _bail)
     timer.daemon = True
     timer.start()
@@ -630,6 +635,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, json_fd=None
         import gc
         gc.collect()
         torch.cuda.empty_cache()
+        publish()
 
     steps2 = 100
     del runner

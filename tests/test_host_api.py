@@ -306,6 +306,31 @@ def test_bench_builds_the_launch_line_for_several_gpus():
     assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
 
 
+def test_bench_result_line_outlives_a_crash_of_the_process():
+    """bench.py hands its line to a process of its own: the last complete line published is printed,
+    exactly once, whether the run returns or aborts inside a library."""
+    import subprocess
+    import sys
+    prog = (
+        "import os, sys, importlib.util\n"
+        f"spec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(ROOT, 'bench.py')!r})\n"
+        "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+        "fd = os.dup(1); os.dup2(2, 1)\n"
+        "k = b.LineKeeper(fd); os.close(fd)\n"
+        "k.publish({'metric': 'm', 'value': 1})\n"
+        "k.publish({'metric': 'm', 'value': 2, 'pad': 'x' * 200000})\n"
+        "print('noise on stdout')\n"
+        "if sys.argv[1] == 'abort': os.abort()\n"
+        "k.publish({'metric': 'm', 'value': 3}); k.close()\n")
+    for how, want, rc_ok in (("abort", 2, False), ("return", 3, True)):
+        p = subprocess.run([sys.executable, "-c", prog, how], capture_output=True, text=True, timeout=60)
+        assert (p.returncode == 0) == rc_ok
+        lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, p.stdout[:300]
+        import json
+        assert json.loads(lines[0])["value"] == want
+
+
 def test_random_symmetric_rows_are_the_rows_of_the_whole_matrix():
     a = la.synth_random_symmetric(5000, 10, 42)
     h = a.row_head_indexes
