@@ -203,6 +203,140 @@ k_spmv_dict(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int 
     if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// The same product with every load from memory issued one workgroup step ahead of its use and next to
+// no arithmetic besides the sums (the form above spends 24 vector instructions per entry on address
+// arithmetic, range tests and selects, and is bound by their issue rate, not by memory).  While a step's
+// rows are summed out of LDS, the next step's window, pattern numbers and far entries are on their way
+// into registers, through buffer descriptors (32-bit offsets, no clamping: what lies outside x reads as
+// zero and is never used).  The far entries are fetched for every row at the (at most kDictFar) distinct
+// far offsets the dictionary holds, whatever the row's pattern turns out to be, so they do not wait for
+// the pattern numbers; they go to LDS regions of their own behind the window, and a region of zeros
+// stands in for the entries a short row does not have.  The dictionary is rewritten once per workgroup
+// into (value, LDS index relative to the row) pairs, so an entry costs three LDS reads, one add and one
+// multiply-add.  Register sets swap roles from step to step (a copy of a register whose load is in
+// flight would make the compiler wait for it).  WPT = window doubles per thread.
+constexpr int kDictFar = 2;
+typedef double dict_d2 __attribute__((ext_vector_type(2)));
+typedef int dict_i4 __attribute__((ext_vector_type(4)));
+static_assert(kDictRows == 4 && kDictFar == 2, "the register sets below are sized for four rows and two far offsets");
+
+static size_t dict_ahead_lds_bytes(int halo, int patterns, int stride) {
+    return sizeof(double) * (size_t)(kDictSpan + 2 * halo + (kDictFar + 1) * kDictSpan) + (size_t)patterns * stride * 12;
+}
+
+template <int WPT>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
+                  const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
+                  int far0, int far1, const double *__restrict__ x, const double *__restrict__ xdot,
+                  double *__restrict__ y, double *__restrict__ partials, int64_t dot_lo, int64_t dot_hi) {
+    extern __shared__ double win[];  // window | far entries (kDictFar regions) | zeros | dictionary values | indices
+    __shared__ double red[kBlock / 64];
+    const int tid = threadIdx.x;
+    const int wlen = kDictSpan + 2 * halo;
+    double *s_far = win + wlen;
+    double *s_zero = s_far + kDictFar * kDictSpan;
+    double *s_val = s_zero + kDictSpan;
+    int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + patterns * stride);
+    for (int i = tid; i < patterns * stride; i += kBlock) {
+        const int off = doff[i];
+        s_val[i] = dval[i];
+        int e;
+        if (i % stride >= dlen[i / stride]) e = (int)(s_zero - win);            // no such entry: times zero
+        else if (off >= -halo && off <= halo) e = halo + off;                    // in the window
+        else e = wlen + (off == far0 ? 0 : kDictSpan);                           // in a far region
+        s_idx[i] = e;
+        if (i % stride >= dlen[i / stride]) s_val[i] = 0.0;
+    }
+    for (int i = tid; i < kDictSpan; i += kBlock) s_zero[i] = 0.0;
+    const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
+    const int64_t per_xcd = (chunks + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > chunks) c_end = chunks;
+    const int64_t c_first = xcd * per_xcd + slot;
+    // n_ext < 2^29 and n < 2^31 (checked by the launcher): byte offsets fit 32 bits
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(uint32_t)((uint64_t)n_ext << 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpat =
+        __builtin_amdgcn_make_buffer_rsrc((void *)pattern, 0, (int)(uint32_t)((uint64_t)n << 1), 0x00020000);
+    double acc = 0.0;
+    double W[WPT];
+
+    auto load_x = [&](int64_t index) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, (int)((uint32_t)index << 3), 0, 0));
+    };
+    auto load_window = [&](int64_t row0) {
+#pragma unroll
+        for (int k = 0; k < WPT; ++k) W[k] = load_x(row0 - halo + k * kBlock + tid);
+    };
+    auto load_rows = [&](int64_t row0, dict_i4 &P, dict_d2 (&XF)[kDictRows]) {
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            const int64_t r = row0 + u * kBlock + tid;
+            P[u] = (int)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rpat, (int)((uint32_t)r << 1), 0, 0);
+            XF[u] = dict_d2{load_x(r + far0), load_x(r + far1)};
+        }
+    };
+    auto step = [&](int64_t c, dict_i4 &P, dict_d2 (&XF)[kDictRows], dict_i4 &Pn, dict_d2 (&XFn)[kDictRows]) {
+        const int64_t row0 = c * kDictSpan;
+        __syncthreads();  // the previous step's readers are done (and the dictionary is in place)
+#pragma unroll
+        for (int k = 0; k < WPT; ++k)
+            if (k * kBlock + tid < wlen) win[k * kBlock + tid] = W[k];
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            s_far[u * kBlock + tid] = XF[u].x;
+            s_far[kDictSpan + u * kBlock + tid] = XF[u].y;
+        }
+        // the next step's loads (the last step loads its own rows again)
+        const int64_t cn = c + slots < c_end ? c + slots : c;
+        load_window(cn * kDictSpan);
+        load_rows(cn * kDictSpan, Pn, XFn);
+        __syncthreads();
+        int base[kDictRows];
+        double sum[kDictRows];
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            base[u] = P[u] * stride;
+            sum[u] = 0.0;
+        }
+        for (int j = 0; j < stride; ++j) {
+#pragma unroll
+            for (int u = 0; u < kDictRows; ++u)
+                sum[u] += s_val[base[u] + j] * win[u * kBlock + tid + s_idx[base[u] + j]];
+        }
+#pragma unroll
+        for (int u = 0; u < kDictRows; ++u) {
+            const int64_t r = row0 + u * kBlock + tid;
+            if (r < n) {
+                __builtin_nontemporal_store(sum[u], y + r);
+                double xd = win[u * kBlock + tid + halo];
+                if (xdot != x) xd = xdot[r];
+                const double t = xd * sum[u];
+                acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
+            }
+        }
+    };
+
+    if (c_first < c_end) {
+        dict_i4 PA, PB;
+        dict_d2 XA[kDictRows], XB[kDictRows];
+        load_window(c_first * kDictSpan);
+        load_rows(c_first * kDictSpan, PA, XA);
+        int64_t c = c_first;
+        for (; c + slots < c_end; c += 2 * slots) {
+            step(c, PA, XA, PB, XB);
+            step(c + slots, PB, XB, PA, XA);
+        }
+        if (c < c_end) step(c, PA, XA, PB, XB);
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 void Engine::free_dict() {
     (void)hipFree(d_pattern);
     (void)hipFree(d_dlen);
@@ -213,6 +347,7 @@ void Engine::free_dict() {
     d_doff = nullptr;
     d_dval = nullptr;
     dict_patterns = 0;
+    dict_blocks = 0;
 }
 
 // dict_patterns > 0 afterwards when the matrix is a dictionary of at most 65535 row patterns of at
@@ -344,6 +479,23 @@ int Engine::build_dict() {
     }
     dict_patterns = count;
     dict_stride = stride;
+    // the distinct offsets beyond the window: at most two of them let the SpMV fetch them ahead of the
+    // pattern numbers
+    dict_far_count = 0;
+    dict_far[0] = dict_far[1] = 0;
+    for (int p = 0; p < count && dict_far_count >= 0; ++p)
+        for (int j = 0; j < hlen[(size_t)p]; ++j) {
+            const int off = hoff[(size_t)p * stride + j], mag = off < 0 ? -off : off;
+            if (mag <= dict_halo) continue;
+            int f = 0;
+            while (f < dict_far_count && dict_far[f] != off) ++f;
+            if (f < dict_far_count) continue;
+            if (dict_far_count == 2) {
+                dict_far_count = -1;  // more than the ahead-of-time form holds
+                break;
+            }
+            dict_far[dict_far_count++] = off;
+        }
     return 0;
 }
 
@@ -355,7 +507,37 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     size_t win_bytes = sizeof(double) * (size_t)(kDictSpan + 2 * dict_halo);
     if (dict_patterns * dict_stride <= kDictLdsEntries)
         win_bytes += (size_t)dict_patterns * dict_stride * 12 + (size_t)dict_patterns * 4;
-    if (dict_patterns * dict_stride <= kDictLdsEntries)
+    // LANCZOS_HIP_DICT_AHEAD=0 keeps the form that loads inside the step
+    static const bool ahead_env = !(getenv("LANCZOS_HIP_DICT_AHEAD") && atoi(getenv("LANCZOS_HIP_DICT_AHEAD")) == 0);
+    const int wpt = (kDictSpan + 2 * dict_halo + kBlock - 1) / kBlock;
+    if (ahead_env && dict_patterns * dict_stride <= kDictLdsEntries && dict_far_count >= 0 && n_ext > 0 &&
+        n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31) &&
+        dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
+        const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
+        // one round of resident workgroups, each walking many steps
+#define LZ_DICT_AHEAD(WPT)                                                                                           \
+    do {                                                                                                             \
+        if (dict_blocks == 0) {                                                                                      \
+            int occ = 0;                                                                                             \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT>, kBlock, lds) !=           \
+                    hipSuccess || occ < 1)                                                                           \
+                occ = 1;                                                                                             \
+            dict_blocks =                                                                                            \
+                (int)std::min<int64_t>(std::min<int64_t>((int64_t)cus * occ, max_blocks), (chunks + 7) / 8 * 8);     \
+        }                                                                                                            \
+        blocks = dict_blocks;                                                                                        \
+        *nparts = blocks;                                                                                            \
+        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT>), dim3(blocks), dim3(kBlock), lds, stream, n, n_ext,              \
+                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
+                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
+                           (int)dict_far[0], (int)dict_far[1], x, xdot, y, d_partials, dot_lo, dot_hi);              \
+    } while (0)
+        if (wpt <= 6) LZ_DICT_AHEAD(6);
+        else if (wpt <= 8) LZ_DICT_AHEAD(8);
+        else if (wpt <= 12) LZ_DICT_AHEAD(12);
+        else LZ_DICT_AHEAD(20);
+#undef LZ_DICT_AHEAD
+    } else if (dict_patterns * dict_stride <= kDictLdsEntries)
         hipLaunchKernelGGL((k_spmv_dict<true>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
                            (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials, dot_lo, dot_hi);

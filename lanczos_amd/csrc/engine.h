@@ -114,6 +114,9 @@ struct Engine {
     int32_t *d_dlen = nullptr, *d_doff = nullptr;  // [patterns], [patterns][dict_stride]
     double *d_dval = nullptr;
     int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
+    int dict_blocks = 0;       // grid of the ahead-of-time form: one round of resident workgroups
+    int dict_far_count = -1;   // distinct column offsets beyond the LDS window (-1: more than two)
+    int32_t dict_far[2] = {0, 0};
     // operator supplied by the caller as a host function (the reference's Matvec_General plugin,
     // src/lanczos.h:5): the product goes through two pinned host vectors, everything else stays here
     lanczos_hip_matvec_fn *ext_matvec = nullptr;
