@@ -220,17 +220,33 @@ typedef double dict_d2 __attribute__((ext_vector_type(2)));
 typedef int dict_i4 __attribute__((ext_vector_type(4)));
 static_assert(kDictRows == 4 && kDictFar == 2, "the register sets below are sized for four rows and two far offsets");
 
+typedef unsigned int dict_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int dict_u4 __attribute__((ext_vector_type(4)));
+
 static size_t dict_ahead_lds_bytes(int halo, int patterns, int stride) {
-    return sizeof(double) * (size_t)(kDictSpan + 2 * halo + (kDictFar + 1) * kDictSpan) + (size_t)patterns * stride * 12;
+    return sizeof(double) * (size_t)(kDictSpan + 2 * halo + (kDictFar + 1) * kDictSpan) + (size_t)patterns * stride * 12 +
+           sizeof(uint16_t) * kDictSpan + 8;
 }
 
-template <int WPT>
+// WIDE (far offsets and the halo even, so that no 16-byte load straddles the start of x): the window
+// and the far entries are loaded two doubles, the pattern numbers four rows per instruction, and the
+// sums of neighbouring lanes are paired for 16-byte stores -- ten memory instructions per thread and step
+// in place of twenty-two (this kernel's loads are bound by the rate at which the addresser takes
+// instructions, 64 addresses each whatever their width).  The pattern numbers go through LDS to the
+// lanes that sum their rows.
+struct DictRegs {
+    dict_i4 p;            // narrow: pattern numbers of this thread's four rows
+    dict_d2 xf[4];        // narrow: [row](far0, far1); wide: [half * 2 + far](rows 2i, 2i + 1)
+    dict_u2 pq;           // wide: pattern numbers of rows 4 tid .. 4 tid + 3
+};
+
+template <int WPT, bool WIDE>
 __global__ void __launch_bounds__(kBlock)
 k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                   const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                   int far0, int far1, const double *__restrict__ x, const double *__restrict__ xdot,
                   double *__restrict__ y, double *__restrict__ partials, int64_t dot_lo, int64_t dot_hi) {
-    extern __shared__ double win[];  // window | far entries (kDictFar regions) | zeros | dictionary values | indices
+    extern __shared__ double win[];  // window | far entries (kDictFar regions) | zeros | dictionary values | indices | patterns
     __shared__ double red[kBlock / 64];
     const int tid = threadIdx.x;
     const int wlen = kDictSpan + 2 * halo;
@@ -238,15 +254,16 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     double *s_zero = s_far + kDictFar * kDictSpan;
     double *s_val = s_zero + kDictSpan;
     int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + patterns * stride);
+    uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + patterns * stride + ((patterns * stride) & 1));
     for (int i = tid; i < patterns * stride; i += kBlock) {
         const int off = doff[i];
-        s_val[i] = dval[i];
+        const bool absent = i % stride >= dlen[i / stride];
         int e;
-        if (i % stride >= dlen[i / stride]) e = (int)(s_zero - win);            // no such entry: times zero
+        if (absent) e = (int)(s_zero - win);                                     // no such entry: zero times zero
         else if (off >= -halo && off <= halo) e = halo + off;                    // in the window
         else e = wlen + (off == far0 ? 0 : kDictSpan);                           // in a far region
         s_idx[i] = e;
-        if (i % stride >= dlen[i / stride]) s_val[i] = 0.0;
+        s_val[i] = absent ? 0.0 : dval[i];
     }
     for (int i = tid; i < kDictSpan; i += kBlock) s_zero[i] = 0.0;
     const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
@@ -255,50 +272,78 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     int64_t c_end = (xcd + 1) * per_xcd;
     if (c_end > chunks) c_end = chunks;
     const int64_t c_first = xcd * per_xcd + slot;
-    // n_ext < 2^29 and n < 2^31 (checked by the launcher): byte offsets fit 32 bits
+    // n_ext < 2^29 and n < 2^31 (checked by the launcher): byte offsets fit 32 bits.  The pattern array's
+    // descriptor ends at the next multiple of four bytes (inside the allocation).
     const __amdgpu_buffer_rsrc_t rx =
         __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(uint32_t)((uint64_t)n_ext << 3), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rpat =
-        __builtin_amdgcn_make_buffer_rsrc((void *)pattern, 0, (int)(uint32_t)((uint64_t)n << 1), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpat = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)pattern, 0, (int)(uint32_t)((((uint64_t)n << 1) + 3) & ~(uint64_t)3), 0x00020000);
     double acc = 0.0;
-    double W[WPT];
+    dict_d2 W[WPT / 2];
 
     auto load_x = [&](int64_t index) -> double {
         return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rx, (int)((uint32_t)index << 3), 0, 0));
     };
-    auto load_window = [&](int64_t row0) {
-#pragma unroll
-        for (int k = 0; k < WPT; ++k) W[k] = load_x(row0 - halo + k * kBlock + tid);
+    auto load_x2 = [&](int64_t index) -> dict_d2 {
+        return __builtin_bit_cast(dict_d2, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)((uint32_t)index << 3), 0, 0));
     };
-    auto load_rows = [&](int64_t row0, dict_i4 &P, dict_d2 (&XF)[kDictRows]) {
+    auto load_ahead = [&](int64_t row0, DictRegs &R) {
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int u = 0; u < kDictRows; ++u) {
-            const int64_t r = row0 + u * kBlock + tid;
-            P[u] = (int)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rpat, (int)((uint32_t)r << 1), 0, 0);
-            XF[u] = dict_d2{load_x(r + far0), load_x(r + far1)};
+            for (int k = 0; k < WPT / 2; ++k) W[k] = load_x2(row0 - halo + 2 * (k * kBlock + tid));
+            R.pq = __builtin_amdgcn_raw_buffer_load_b64(rpat, (int)((uint32_t)(row0 + 4 * tid) << 1), 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int64_t r = row0 + 2 * (h * kBlock + tid);
+                R.xf[h * 2 + 0] = load_x2(r + far0);
+                R.xf[h * 2 + 1] = load_x2(r + far1);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPT / 2; ++k)
+                W[k] = dict_d2{load_x(row0 - halo + (2 * k) * kBlock + tid), load_x(row0 - halo + (2 * k + 1) * kBlock + tid)};
+#pragma unroll
+            for (int u = 0; u < kDictRows; ++u) {
+                const int64_t r = row0 + u * kBlock + tid;
+                R.p[u] = (int)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rpat, (int)((uint32_t)r << 1), 0, 0);
+                R.xf[u] = dict_d2{load_x(r + far0), load_x(r + far1)};
+            }
         }
     };
-    auto step = [&](int64_t c, dict_i4 &P, dict_d2 (&XF)[kDictRows], dict_i4 &Pn, dict_d2 (&XFn)[kDictRows]) {
+    auto step = [&](int64_t c, DictRegs &R, DictRegs &Rn) {
         const int64_t row0 = c * kDictSpan;
         __syncthreads();  // the previous step's readers are done (and the dictionary is in place)
+        if constexpr (WIDE) {
 #pragma unroll
-        for (int k = 0; k < WPT; ++k)
-            if (k * kBlock + tid < wlen) win[k * kBlock + tid] = W[k];
+            for (int k = 0; k < WPT / 2; ++k)
+                if (2 * (k * kBlock + tid) < wlen) *reinterpret_cast<dict_d2 *>(win + 2 * (k * kBlock + tid)) = W[k];
+            *reinterpret_cast<dict_u2 *>(s_pat + 4 * tid) = R.pq;
 #pragma unroll
-        for (int u = 0; u < kDictRows; ++u) {
-            s_far[u * kBlock + tid] = XF[u].x;
-            s_far[kDictSpan + u * kBlock + tid] = XF[u].y;
+            for (int h = 0; h < 2; ++h) {
+                *reinterpret_cast<dict_d2 *>(s_far + 2 * (h * kBlock + tid)) = R.xf[h * 2 + 0];
+                *reinterpret_cast<dict_d2 *>(s_far + kDictSpan + 2 * (h * kBlock + tid)) = R.xf[h * 2 + 1];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < WPT / 2; ++k) {
+                if ((2 * k) * kBlock + tid < wlen) win[(2 * k) * kBlock + tid] = W[k].x;
+                if ((2 * k + 1) * kBlock + tid < wlen) win[(2 * k + 1) * kBlock + tid] = W[k].y;
+            }
+#pragma unroll
+            for (int u = 0; u < kDictRows; ++u) {
+                s_far[u * kBlock + tid] = R.xf[u].x;
+                s_far[kDictSpan + u * kBlock + tid] = R.xf[u].y;
+            }
         }
         // the next step's loads (the last step loads its own rows again)
         const int64_t cn = c + slots < c_end ? c + slots : c;
-        load_window(cn * kDictSpan);
-        load_rows(cn * kDictSpan, Pn, XFn);
+        load_ahead(cn * kDictSpan, Rn);
         __syncthreads();
         int base[kDictRows];
         double sum[kDictRows];
 #pragma unroll
         for (int u = 0; u < kDictRows; ++u) {
-            base[u] = P[u] * stride;
+            base[u] = (WIDE ? (int)s_pat[u * kBlock + tid] : R.p[u]) * stride;
             sum[u] = 0.0;
         }
         for (int j = 0; j < stride; ++j) {
@@ -310,26 +355,38 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
         for (int u = 0; u < kDictRows; ++u) {
             const int64_t r = row0 + u * kBlock + tid;
             if (r < n) {
-                __builtin_nontemporal_store(sum[u], y + r);
+                if constexpr (!WIDE) __builtin_nontemporal_store(sum[u], y + r);
                 double xd = win[u * kBlock + tid + halo];
                 if (xdot != x) xd = xdot[r];
                 const double t = xd * sum[u];
                 acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
             }
         }
+        if constexpr (WIDE) {
+            // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first two row
+            // sets, the odd lane those of the last two
+            const bool odd = tid & 1;
+            const double give0 = odd ? sum[0] : sum[2], give1 = odd ? sum[1] : sum[3];
+            const double got0 = __shfl_xor(give0, 1), got1 = __shfl_xor(give1, 1);
+            const dict_d2 s0 = odd ? dict_d2{got0, sum[2]} : dict_d2{sum[0], got0};
+            const dict_d2 s1 = odd ? dict_d2{got1, sum[3]} : dict_d2{sum[1], got1};
+            const int64_t r0 = row0 + (odd ? 2 : 0) * kBlock + (tid & ~1), r1 = r0 + kBlock;
+            if (r0 + 1 < n) __builtin_nontemporal_store(s0, reinterpret_cast<dict_d2 *>(y + r0));
+            else if (r0 < n) __builtin_nontemporal_store(s0.x, y + r0);
+            if (r1 + 1 < n) __builtin_nontemporal_store(s1, reinterpret_cast<dict_d2 *>(y + r1));
+            else if (r1 < n) __builtin_nontemporal_store(s1.x, y + r1);
+        }
     };
 
     if (c_first < c_end) {
-        dict_i4 PA, PB;
-        dict_d2 XA[kDictRows], XB[kDictRows];
-        load_window(c_first * kDictSpan);
-        load_rows(c_first * kDictSpan, PA, XA);
+        DictRegs RA, RB;
+        load_ahead(c_first * kDictSpan, RA);
         int64_t c = c_first;
         for (; c + slots < c_end; c += 2 * slots) {
-            step(c, PA, XA, PB, XB);
-            step(c + slots, PB, XB, PA, XA);
+            step(c, RA, RB);
+            step(c + slots, RB, RA);
         }
-        if (c < c_end) step(c, PA, XA, PB, XB);
+        if (c < c_end) step(c, RA, RB);
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -473,6 +530,7 @@ int Engine::build_dict() {
             const int off = hoff[(size_t)p * stride + j], mag = off < 0 ? -off : off;
             if (mag <= kDictMaxHalo) dict_halo = std::max(dict_halo, mag);
         }
+    dict_halo = (dict_halo + 1) & ~1;  // even: the window then starts at an even index of x
     if (flags[1]) {  // two different rows behind one hash: keep the CRS kernels
         free_dict();
         return 0;
@@ -515,11 +573,11 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
         const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
         // one round of resident workgroups, each walking many steps
-#define LZ_DICT_AHEAD(WPT)                                                                                           \
+#define LZ_DICT_AHEAD_W(WPT, WIDE)                                                                                         \
     do {                                                                                                             \
         if (dict_blocks == 0) {                                                                                      \
             int occ = 0;                                                                                             \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT>, kBlock, lds) !=           \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT, WIDE>, kBlock, lds) !=           \
                     hipSuccess || occ < 1)                                                                           \
                 occ = 1;                                                                                             \
             dict_blocks =                                                                                            \
@@ -527,16 +585,25 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         }                                                                                                            \
         blocks = dict_blocks;                                                                                        \
         *nparts = blocks;                                                                                            \
-        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT>), dim3(blocks), dim3(kBlock), lds, stream, n, n_ext,              \
+        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT, WIDE>), dim3(blocks), dim3(kBlock), lds, stream, n, n_ext,              \
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
                            (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
                            (int)dict_far[0], (int)dict_far[1], x, xdot, y, d_partials, dot_lo, dot_hi);              \
+    } while (0)
+        // 16-byte loads when no pair of doubles can straddle the start of x (LANCZOS_HIP_DICT_WIDE=0: never)
+        static const bool wide_env = !(getenv("LANCZOS_HIP_DICT_WIDE") && atoi(getenv("LANCZOS_HIP_DICT_WIDE")) == 0);
+        const bool wide = wide_env && !(dict_far[0] & 1) && !(dict_far[1] & 1) && !(dict_halo & 1);
+#define LZ_DICT_AHEAD(WPT)                 \
+    do {                                   \
+        if (wide) LZ_DICT_AHEAD_W(WPT, true); \
+        else LZ_DICT_AHEAD_W(WPT, false);  \
     } while (0)
         if (wpt <= 6) LZ_DICT_AHEAD(6);
         else if (wpt <= 8) LZ_DICT_AHEAD(8);
         else if (wpt <= 12) LZ_DICT_AHEAD(12);
         else LZ_DICT_AHEAD(20);
 #undef LZ_DICT_AHEAD
+#undef LZ_DICT_AHEAD_W
     } else if (dict_patterns * dict_stride <= kDictLdsEntries)
         hipLaunchKernelGGL((k_spmv_dict<true>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
