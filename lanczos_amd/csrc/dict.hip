@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "engine.h"
@@ -240,14 +241,16 @@ struct DictRegs {
     dict_u2 pq;           // wide: pattern numbers of rows 4 tid .. 4 tid + 3
 };
 
-template <int WPT, bool WIDE>
-__global__ void __launch_bounds__(kBlock)
+template <int WPT, bool WIDE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                   const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                   int far0, int far1, const double *__restrict__ x, const double *__restrict__ xdot,
                   double *__restrict__ y, double *__restrict__ partials, int64_t dot_lo, int64_t dot_hi) {
     extern __shared__ double win[];  // window | far entries (kDictFar regions) | zeros | dictionary values | indices | patterns
-    __shared__ double red[kBlock / 64];
+    constexpr int ROWS = kDictSpan / BLOCK;   // rows per thread: 4 (256 threads) or 2 (512 threads)
+    static_assert(ROWS == 2 || ROWS == 4, "a step covers kDictSpan rows with 256 or 512 threads");
+    __shared__ double red[BLOCK / 64];
     const int tid = threadIdx.x;
     const int wlen = kDictSpan + 2 * halo;
     double *s_far = win + wlen;
@@ -255,7 +258,7 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     double *s_val = s_zero + kDictSpan;
     int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + patterns * stride);
     uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + patterns * stride + ((patterns * stride) & 1));
-    for (int i = tid; i < patterns * stride; i += kBlock) {
+    for (int i = tid; i < patterns * stride; i += BLOCK) {
         const int off = doff[i];
         const bool absent = i % stride >= dlen[i / stride];
         int e;
@@ -265,7 +268,7 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
         s_idx[i] = e;
         s_val[i] = absent ? 0.0 : dval[i];
     }
-    for (int i = tid; i < kDictSpan; i += kBlock) s_zero[i] = 0.0;
+    for (int i = tid; i < kDictSpan; i += BLOCK) s_zero[i] = 0.0;
     const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
     const int64_t per_xcd = (chunks + 7) >> 3;
     const int64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
@@ -290,21 +293,24 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     auto load_ahead = [&](int64_t row0, DictRegs &R) {
         if constexpr (WIDE) {
 #pragma unroll
-            for (int k = 0; k < WPT / 2; ++k) W[k] = load_x2(row0 - halo + 2 * (k * kBlock + tid));
-            R.pq = __builtin_amdgcn_raw_buffer_load_b64(rpat, (int)((uint32_t)(row0 + 4 * tid) << 1), 0, 0);
+            for (int k = 0; k < WPT / 2; ++k) W[k] = load_x2(row0 - halo + 2 * (k * BLOCK + tid));
+            if constexpr (ROWS == 4)
+                R.pq = __builtin_amdgcn_raw_buffer_load_b64(rpat, (int)((uint32_t)(row0 + 4 * tid) << 1), 0, 0);
+            else
+                R.pq.x = __builtin_amdgcn_raw_buffer_load_b32(rpat, (int)((uint32_t)(row0 + 2 * tid) << 1), 0, 0);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int64_t r = row0 + 2 * (h * kBlock + tid);
+            for (int h = 0; h < ROWS / 2; ++h) {
+                const int64_t r = row0 + 2 * (h * BLOCK + tid);
                 R.xf[h * 2 + 0] = load_x2(r + far0);
                 R.xf[h * 2 + 1] = load_x2(r + far1);
             }
         } else {
 #pragma unroll
             for (int k = 0; k < WPT / 2; ++k)
-                W[k] = dict_d2{load_x(row0 - halo + (2 * k) * kBlock + tid), load_x(row0 - halo + (2 * k + 1) * kBlock + tid)};
+                W[k] = dict_d2{load_x(row0 - halo + (2 * k) * BLOCK + tid), load_x(row0 - halo + (2 * k + 1) * BLOCK + tid)};
 #pragma unroll
-            for (int u = 0; u < kDictRows; ++u) {
-                const int64_t r = row0 + u * kBlock + tid;
+            for (int u = 0; u < ROWS; ++u) {
+                const int64_t r = row0 + u * BLOCK + tid;
                 R.p[u] = (int)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rpat, (int)((uint32_t)r << 1), 0, 0);
                 R.xf[u] = dict_d2{load_x(r + far0), load_x(r + far1)};
             }
@@ -316,65 +322,66 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
         if constexpr (WIDE) {
 #pragma unroll
             for (int k = 0; k < WPT / 2; ++k)
-                if (2 * (k * kBlock + tid) < wlen) *reinterpret_cast<dict_d2 *>(win + 2 * (k * kBlock + tid)) = W[k];
-            *reinterpret_cast<dict_u2 *>(s_pat + 4 * tid) = R.pq;
+                if (2 * (k * BLOCK + tid) < wlen) *reinterpret_cast<dict_d2 *>(win + 2 * (k * BLOCK + tid)) = W[k];
+            if constexpr (ROWS == 4) *reinterpret_cast<dict_u2 *>(s_pat + 4 * tid) = R.pq;
+            else *reinterpret_cast<uint32_t *>(s_pat + 2 * tid) = R.pq.x;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                *reinterpret_cast<dict_d2 *>(s_far + 2 * (h * kBlock + tid)) = R.xf[h * 2 + 0];
-                *reinterpret_cast<dict_d2 *>(s_far + kDictSpan + 2 * (h * kBlock + tid)) = R.xf[h * 2 + 1];
+            for (int h = 0; h < ROWS / 2; ++h) {
+                *reinterpret_cast<dict_d2 *>(s_far + 2 * (h * BLOCK + tid)) = R.xf[h * 2 + 0];
+                *reinterpret_cast<dict_d2 *>(s_far + kDictSpan + 2 * (h * BLOCK + tid)) = R.xf[h * 2 + 1];
             }
         } else {
 #pragma unroll
             for (int k = 0; k < WPT / 2; ++k) {
-                if ((2 * k) * kBlock + tid < wlen) win[(2 * k) * kBlock + tid] = W[k].x;
-                if ((2 * k + 1) * kBlock + tid < wlen) win[(2 * k + 1) * kBlock + tid] = W[k].y;
+                if ((2 * k) * BLOCK + tid < wlen) win[(2 * k) * BLOCK + tid] = W[k].x;
+                if ((2 * k + 1) * BLOCK + tid < wlen) win[(2 * k + 1) * BLOCK + tid] = W[k].y;
             }
 #pragma unroll
-            for (int u = 0; u < kDictRows; ++u) {
-                s_far[u * kBlock + tid] = R.xf[u].x;
-                s_far[kDictSpan + u * kBlock + tid] = R.xf[u].y;
+            for (int u = 0; u < ROWS; ++u) {
+                s_far[u * BLOCK + tid] = R.xf[u].x;
+                s_far[kDictSpan + u * BLOCK + tid] = R.xf[u].y;
             }
         }
         // the next step's loads (the last step loads its own rows again)
         const int64_t cn = c + slots < c_end ? c + slots : c;
         load_ahead(cn * kDictSpan, Rn);
         __syncthreads();
-        int base[kDictRows];
-        double sum[kDictRows];
+        int base[ROWS];
+        double sum[ROWS];
 #pragma unroll
-        for (int u = 0; u < kDictRows; ++u) {
-            base[u] = (WIDE ? (int)s_pat[u * kBlock + tid] : R.p[u]) * stride;
+        for (int u = 0; u < ROWS; ++u) {
+            base[u] = (WIDE ? (int)s_pat[u * BLOCK + tid] : R.p[u]) * stride;
             sum[u] = 0.0;
         }
         for (int j = 0; j < stride; ++j) {
 #pragma unroll
-            for (int u = 0; u < kDictRows; ++u)
-                sum[u] += s_val[base[u] + j] * win[u * kBlock + tid + s_idx[base[u] + j]];
+            for (int u = 0; u < ROWS; ++u)
+                sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + s_idx[base[u] + j]];
         }
 #pragma unroll
-        for (int u = 0; u < kDictRows; ++u) {
-            const int64_t r = row0 + u * kBlock + tid;
+        for (int u = 0; u < ROWS; ++u) {
+            const int64_t r = row0 + u * BLOCK + tid;
             if (r < n) {
                 if constexpr (!WIDE) __builtin_nontemporal_store(sum[u], y + r);
-                double xd = win[u * kBlock + tid + halo];
+                double xd = win[u * BLOCK + tid + halo];
                 if (xdot != x) xd = xdot[r];
                 const double t = xd * sum[u];
                 acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
             }
         }
         if constexpr (WIDE) {
-            // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first two row
-            // sets, the odd lane those of the last two
+            // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first half of the
+            // row sets, the odd lane those of the second half
             const bool odd = tid & 1;
-            const double give0 = odd ? sum[0] : sum[2], give1 = odd ? sum[1] : sum[3];
-            const double got0 = __shfl_xor(give0, 1), got1 = __shfl_xor(give1, 1);
-            const dict_d2 s0 = odd ? dict_d2{got0, sum[2]} : dict_d2{sum[0], got0};
-            const dict_d2 s1 = odd ? dict_d2{got1, sum[3]} : dict_d2{sum[1], got1};
-            const int64_t r0 = row0 + (odd ? 2 : 0) * kBlock + (tid & ~1), r1 = r0 + kBlock;
-            if (r0 + 1 < n) __builtin_nontemporal_store(s0, reinterpret_cast<dict_d2 *>(y + r0));
-            else if (r0 < n) __builtin_nontemporal_store(s0.x, y + r0);
-            if (r1 + 1 < n) __builtin_nontemporal_store(s1, reinterpret_cast<dict_d2 *>(y + r1));
-            else if (r1 < n) __builtin_nontemporal_store(s1.x, y + r1);
+#pragma unroll
+            for (int q = 0; q < ROWS / 2; ++q) {
+                const double mine = odd ? sum[ROWS / 2 + q] : sum[q];
+                const double got = __shfl_xor(odd ? sum[q] : sum[ROWS / 2 + q], 1);
+                const dict_d2 s2 = odd ? dict_d2{got, mine} : dict_d2{mine, got};
+                const int64_t r2 = row0 + ((odd ? ROWS / 2 : 0) + q) * BLOCK + (tid & ~1);
+                if (r2 + 1 < n) __builtin_nontemporal_store(s2, reinterpret_cast<dict_d2 *>(y + r2));
+                else if (r2 < n) __builtin_nontemporal_store(s2.x, y + r2);
+            }
         }
     };
 
@@ -391,7 +398,155 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x == 0) {
+        double t = (red[0] + red[1]) + (red[2] + red[3]);
+        if constexpr (BLOCK == 512) t += (red[4] + red[5]) + (red[6] + red[7]);
+        partials[blockIdx.x] = t;
+    }
+}
+
+// Grids in three dimensions: the two far offsets are -F and +F (one plane of the grid back and ahead).
+// When F is a multiple of the step's rows, a workgroup that walks from plane to plane -- rows
+// [c, c + kDictSpan) of plane z, then the same rows of plane z + 1 -- finds its far entries in the
+// windows of the step before and the step after.  Three windows stay in LDS (a ring), every step loads
+// one, and x is fetched 1.5 times per product (the windows' halos) in place of 3.5 times; the form above
+// is bound by the rate of L1 misses, which this one halves.  The planes are cut into segments so that
+// every CU has its workgroups; a segment loads one plane before and one after its own.  Index tables
+// for the three positions of the ring are built once per workgroup; the step is instantiated per position.
+constexpr int kPlanesBlock = 512;
+
+static size_t dict_planes_lds_bytes(int halo, int patterns, int stride) {
+    return sizeof(double) * (size_t)(3 * (kDictSpan + 2 * halo) + kDictSpan) + (size_t)patterns * stride * (8 + 3 * 4) +
+           sizeof(uint16_t) * kDictSpan + 16;
+}
+
+template <int WPT>
+__global__ void __launch_bounds__(kPlanesBlock)
+k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
+                   const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
+                   int far_step, int cols, int planes, int seg_len, int segs, const double *__restrict__ x,
+                   const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
+                   int64_t dot_lo, int64_t dot_hi) {
+    constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
+    static_assert(ROWS == 2, "two rows per thread");
+    extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
+    __shared__ double red[BLOCK / 64];
+    const int tid = threadIdx.x;
+    const int wlen = kDictSpan + 2 * halo;
+    const int tab = patterns * stride;
+    double *s_zero = win + 3 * wlen;
+    double *s_val = s_zero + kDictSpan;
+    int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + tab);
+    uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + 3 * tab + ((3 * tab) & 1));
+    for (int i = tid; i < tab; i += BLOCK) {
+        const int off = doff[i];
+        const bool absent = i % stride >= dlen[i / stride];
+        s_val[i] = absent ? 0.0 : dval[i];
+#pragma unroll
+        for (int rot = 0; rot < 3; ++rot) {
+            // ring slot `rot` holds this step's window, the slot before it the previous plane's, the slot after it the next one's
+            int e;
+            if (absent) e = 3 * wlen;
+            else if (off >= -halo && off <= halo) e = rot * wlen + halo + off;
+            else e = ((rot + (off < 0 ? 2 : 1)) % 3) * wlen + halo;
+            s_idx[rot * tab + i] = e;
+        }
+    }
+    for (int i = tid; i < kDictSpan; i += BLOCK) s_zero[i] = 0.0;
+    // work item = (column of steps, segment of planes); XCD b % 8 takes a contiguous eighth of the items
+    const int64_t items = (int64_t)cols * segs;
+    const int64_t per_xcd = (items + 7) >> 3;
+    const int64_t item = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    const bool live = (int64_t)(blockIdx.x >> 3) < per_xcd && item < items;
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(uint32_t)((uint64_t)n_ext << 3), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpat = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)pattern, 0, (int)(uint32_t)((((uint64_t)n << 1) + 3) & ~(uint64_t)3), 0x00020000);
+    double acc = 0.0;
+    if (live) {
+        const int col = (int)(item % cols), seg = (int)(item / cols);
+        const int zb = seg * seg_len, ze = min(zb + seg_len, planes);
+        dict_d2 W[WPT / 2];
+        uint32_t pq;
+        auto row_of = [&](int z) -> int64_t { return ((int64_t)z * cols + col) * kDictSpan; };
+        // a plane outside the grid, or rows past the end, read as zeros (or as rows no entry refers to)
+        auto load_window = [&](int z) {
+            const int64_t row0 = row_of(z);
+#pragma unroll
+            for (int k = 0; k < WPT / 2; ++k)
+                W[k] = __builtin_bit_cast(dict_d2, __builtin_amdgcn_raw_buffer_load_b128(
+                                                       rx, (int)((uint32_t)(row0 - halo + 2 * (k * BLOCK + tid)) << 3), 0, 0));
+        };
+        auto store_window = [&](int slot) {
+#pragma unroll
+            for (int k = 0; k < WPT / 2; ++k)
+                if (2 * (k * BLOCK + tid) < wlen)
+                    *reinterpret_cast<dict_d2 *>(win + slot * wlen + 2 * (k * BLOCK + tid)) = W[k];
+        };
+        auto load_patterns = [&](int z) {
+            pq = __builtin_amdgcn_raw_buffer_load_b32(rpat, (int)((uint32_t)(row_of(z) + 2 * tid) << 1), 0, 0);
+        };
+        auto step = [&](int z, auto rot_tag) {
+            constexpr int ROT = decltype(rot_tag)::value;
+            const int64_t row0 = row_of(z);
+            __syncthreads();  // the previous step's readers are done
+            store_window((ROT + 1) % 3);
+            *reinterpret_cast<uint32_t *>(s_pat + 2 * tid) = pq;
+            if (z + 1 < ze) {
+                load_window(z + 2);
+                load_patterns(z + 1);
+            }
+            __syncthreads();
+            const int32_t *idx = s_idx + ROT * tab;
+            int base[ROWS];
+            double sum[ROWS];
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                base[u] = (int)s_pat[u * BLOCK + tid] * stride;
+                sum[u] = 0.0;
+            }
+            for (int j = 0; j < stride; ++j) {
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + idx[base[u] + j]];
+            }
+#pragma unroll
+            for (int u = 0; u < ROWS; ++u) {
+                const int64_t r = row0 + u * BLOCK + tid;
+                if (r < n) {
+                    double xd = win[ROT * wlen + halo + u * BLOCK + tid];
+                    if (xdot != x) xd = xdot[r];
+                    const double t = xd * sum[u];
+                    acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
+                }
+            }
+            // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first row set, the odd
+            // lane those of the second
+            const bool odd = tid & 1;
+            const double mine = odd ? sum[1] : sum[0];
+            const double got = __shfl_xor(odd ? sum[0] : sum[1], 1);
+            const dict_d2 s2 = odd ? dict_d2{got, mine} : dict_d2{mine, got};
+            const int64_t r2 = row0 + (odd ? BLOCK : 0) + (tid & ~1);
+            if (r2 + 1 < n) __builtin_nontemporal_store(s2, reinterpret_cast<dict_d2 *>(y + r2));
+            else if (r2 < n) __builtin_nontemporal_store(s2.x, y + r2);
+        };
+        // the planes before and of the first step go to ring slots 0 and 1, the one after it waits in registers
+        load_window(zb - 1);
+        store_window(0);
+        load_window(zb);
+        store_window(1);
+        load_window(zb + 1);
+        load_patterns(zb);
+        for (int z = zb; z < ze; z += 3) {
+            step(z, std::integral_constant<int, 1>{});
+            if (z + 1 < ze) step(z + 1, std::integral_constant<int, 2>{});
+            if (z + 2 < ze) step(z + 2, std::integral_constant<int, 0>{});
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
 }
 
 void Engine::free_dict() {
@@ -568,16 +723,60 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     // LANCZOS_HIP_DICT_AHEAD=0 keeps the form that loads inside the step
     static const bool ahead_env = !(getenv("LANCZOS_HIP_DICT_AHEAD") && atoi(getenv("LANCZOS_HIP_DICT_AHEAD")) == 0);
     const int wpt = (kDictSpan + 2 * dict_halo + kBlock - 1) / kBlock;
+    // three-dimensional grids whose plane is a whole number of steps: the plane-walking form
+    static const bool planes_env = !(getenv("LANCZOS_HIP_DICT_PLANES") && atoi(getenv("LANCZOS_HIP_DICT_PLANES")) == 0);
+    if (planes_env && ahead_env && dict_patterns * dict_stride <= kDictLdsEntries && dict_far_count == 2 &&
+        dict_far[0] == -dict_far[1] && std::abs(dict_far[0]) % kDictSpan == 0 && !(dict_halo & 1) && n_ext > 0 &&
+        n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31) &&
+        dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
+        const int cols = std::abs(dict_far[0]) / kDictSpan;
+        const int planes = (int)((chunks + cols - 1) / cols);
+        const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
+        const int w = 2 * (((kDictSpan + 2 * dict_halo) / 2 + kPlanesBlock - 1) / kPlanesBlock);
+        if (planes >= 3) {
+#define LZ_DICT_PLANES(WPT)                                                                                          \
+    do {                                                                                                             \
+        if (dict_blocks == 0) {                                                                                      \
+            int occ = 0;                                                                                             \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_planes<WPT>, kPlanesBlock, lds) !=    \
+                    hipSuccess || occ < 1)                                                                           \
+                occ = 1;                                                                                             \
+            const int64_t want = std::min<int64_t>((int64_t)cus * occ, max_blocks);                                  \
+            dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));                       \
+            dict_seg_len = (planes + dict_segs - 1) / dict_segs;                                                     \
+            dict_segs = (planes + dict_seg_len - 1) / dict_seg_len;                                                  \
+            const int64_t per_xcd = ((int64_t)cols * dict_segs + 7) / 8;                                             \
+            dict_blocks = (int)(per_xcd * 8);                                                                        \
+        }                                                                                                            \
+        blocks = dict_blocks;                                                                                        \
+        *nparts = blocks;                                                                                            \
+        hipLaunchKernelGGL((k_spmv_dict_planes<WPT>), dim3(blocks), dim3(kPlanesBlock), lds, stream, n, n_ext,       \
+                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
+                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
+                           std::abs(dict_far[0]), cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials,     \
+                           dot_lo, dot_hi);                                                                          \
+    } while (0)
+            if ((int64_t)cols * 1 <= max_blocks) {
+                if (w <= 4) LZ_DICT_PLANES(4);
+                else if (w <= 6) LZ_DICT_PLANES(6);
+                else LZ_DICT_PLANES(10);
+#undef LZ_DICT_PLANES
+                const hipError_t stp = hipGetLastError();
+                if (stp != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(stp));
+                return 0;
+            }
+        }
+    }
     if (ahead_env && dict_patterns * dict_stride <= kDictLdsEntries && dict_far_count >= 0 && n_ext > 0 &&
         n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31) &&
         dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
         const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
         // one round of resident workgroups, each walking many steps
-#define LZ_DICT_AHEAD_W(WPT, WIDE)                                                                                         \
+#define LZ_DICT_AHEAD_W(WPT, WIDE, BLK)                                                                                         \
     do {                                                                                                             \
         if (dict_blocks == 0) {                                                                                      \
             int occ = 0;                                                                                             \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT, WIDE>, kBlock, lds) !=           \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT, WIDE, BLK>, BLK, lds) !=           \
                     hipSuccess || occ < 1)                                                                           \
                 occ = 1;                                                                                             \
             dict_blocks =                                                                                            \
@@ -585,7 +784,7 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         }                                                                                                            \
         blocks = dict_blocks;                                                                                        \
         *nparts = blocks;                                                                                            \
-        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT, WIDE>), dim3(blocks), dim3(kBlock), lds, stream, n, n_ext,              \
+        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT, WIDE, BLK>), dim3(blocks), dim3(BLK), lds, stream, n, n_ext,              \
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
                            (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
                            (int)dict_far[0], (int)dict_far[1], x, xdot, y, d_partials, dot_lo, dot_hi);              \
@@ -593,15 +792,25 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         // 16-byte loads when no pair of doubles can straddle the start of x (LANCZOS_HIP_DICT_WIDE=0: never)
         static const bool wide_env = !(getenv("LANCZOS_HIP_DICT_WIDE") && atoi(getenv("LANCZOS_HIP_DICT_WIDE")) == 0);
         const bool wide = wide_env && !(dict_far[0] & 1) && !(dict_far[1] & 1) && !(dict_halo & 1);
-#define LZ_DICT_AHEAD(WPT)                 \
-    do {                                   \
-        if (wide) LZ_DICT_AHEAD_W(WPT, true); \
-        else LZ_DICT_AHEAD_W(WPT, false);  \
+#define LZ_DICT_AHEAD(WPT, BLK)                    \
+    do {                                           \
+        if (wide) LZ_DICT_AHEAD_W(WPT, true, BLK); \
+        else LZ_DICT_AHEAD_W(WPT, false, BLK);     \
     } while (0)
-        if (wpt <= 6) LZ_DICT_AHEAD(6);
-        else if (wpt <= 8) LZ_DICT_AHEAD(8);
-        else if (wpt <= 12) LZ_DICT_AHEAD(12);
-        else LZ_DICT_AHEAD(20);
+        // 512 threads (two rows per thread): twice the wavefronts per CU at the same LDS footprint
+        static const int blk_env = getenv("LANCZOS_HIP_DICT_BLOCK") ? atoi(getenv("LANCZOS_HIP_DICT_BLOCK")) : 512;
+        const int wlen = kDictSpan + 2 * dict_halo;
+        if (blk_env == 512) {
+            const int w = 2 * ((wlen / 2 + 511) / 512);
+            if (w <= 4) LZ_DICT_AHEAD(4, 512);
+            else if (w <= 6) LZ_DICT_AHEAD(6, 512);
+            else LZ_DICT_AHEAD(10, 512);
+        } else {
+            if (wpt <= 6) LZ_DICT_AHEAD(6, 256);
+            else if (wpt <= 8) LZ_DICT_AHEAD(8, 256);
+            else if (wpt <= 12) LZ_DICT_AHEAD(12, 256);
+            else LZ_DICT_AHEAD(20, 256);
+        }
 #undef LZ_DICT_AHEAD
 #undef LZ_DICT_AHEAD_W
     } else if (dict_patterns * dict_stride <= kDictLdsEntries)

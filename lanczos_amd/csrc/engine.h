@@ -115,6 +115,7 @@ struct Engine {
     double *d_dval = nullptr;
     int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
     int dict_blocks = 0;       // grid of the ahead-of-time form: one round of resident workgroups
+    int dict_segs = 0, dict_seg_len = 0;   // plane-walking form: segments of planes per column of steps
     int dict_far_count = -1;   // distinct column offsets beyond the LDS window (-1: more than two)
     int32_t dict_far[2] = {0, 0};
     // operator supplied by the caller as a host function (the reference's Matvec_General plugin,

@@ -176,6 +176,43 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
             assert np.all(np.abs(e.spmv(x2) - want2) <= spmv_tolerance(b, x2)), tail
 
 
+def test_dictionary_spmv_forms_on_grids(gpu):
+    """The dictionary SpMV picks its form from the grid: planes that are a whole number of 1024-row steps
+    are walked plane by plane (N a multiple of 32: one column of steps at 32^3, four at 64^3, nine at 96^3,
+    segments of planes), other even plane sizes take 16-byte loads, odd ones (N = 33, 45: pairs of doubles
+    would straddle the start of x) 8-byte loads, and small grids (N^2 <= 2048) have no far entries at
+    all.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
+    odd vector lengths too, and the alpha partial that goes with them."""
+    for N in (12, 32, 33, 40, 45, 46, 64, 96):
+        a = la.synth_laplacian(3, N)
+        rng = np.random.default_rng(N)
+        x = rng.standard_normal(a.dimension)
+        with la.Engine(a, 4, spmv="dict") as e:
+            assert e.spmv_name.startswith("dict")
+            y = e.spmv(x)
+            e.set_start(x)
+            alpha, _ = e.run(2)
+        with la.Engine(a, 4, spmv="rows") as e:
+            assert e.spmv(x).tobytes() == y.tobytes(), N
+            e.set_start(x)
+            alpha_rows, _ = e.run(2)
+        assert rel_err(alpha, alpha_rows) < 1e-13, N
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        assert np.all(np.abs(y - want) <= spmv_tolerance(a, x)), N
+    # a grid cut off in the middle of a plane (the last plane is partial), and one row fewer (odd length)
+    a = la.synth_laplacian(3, 64)
+    for n in (64 * 64 * 40 + 1500, 64 * 64 * 40 + 1501):
+        h = a.row_head_indexes[:n + 1]
+        keep = a.column_index[:h[-1]] < n
+        head = np.concatenate(([0], np.cumsum(np.add.reduceat(keep.astype(np.int64), h[:-1]))))
+        b = la.CrsMatrix(a.values[:h[-1]][keep], a.column_index[:h[-1]][keep], head)
+        x = np.random.default_rng(n).standard_normal(n)
+        with la.Engine(b, 3, spmv="dict") as e:
+            y = e.spmv(x)
+        with la.Engine(b, 3, spmv="rows") as e:
+            assert e.spmv(x).tobytes() == y.tobytes(), n
+
+
 def test_dictionary_spmv_on_repeating_rows(gpu):
     """One pattern number per row: the same bits as the row-wise kernel (entries in CRS order,
     src/crs.c:172-175), the Lanczos sequences of the oracle, and a clean refusal when rows do not repeat."""
