@@ -107,6 +107,12 @@ typedef struct crs {
  *                          default the row blocks' weights decide)
  *   LANCZOS_HIP_TILE_ROWBITS 11 to 14: rows per block of the tiled SpMV as a power of two (default: even
  *                          schedule 12, 11 for vectors up to 128 MiB; uneven 13, 14 beyond 256 MiB)
+ *   LANCZOS_HIP_ROWS_MASK  0: the row-wise CRS SpMV loads whole tiles instead of ending each group's loads at
+ *                          its last entry (for comparison)
+ *   LANCZOS_HIP_DICT_PLANES / LANCZOS_HIP_DICT_AHEAD / LANCZOS_HIP_DICT_WIDE  0 switches off, in turn, the
+ *                          dictionary SpMV's plane-walking form (3-D grids), its forms that load one step
+ *                          ahead, and their 16-byte loads (for comparison; the results are the same bits);
+ *                          LANCZOS_HIP_DICT_BLOCK 256 runs the ahead form with 256-thread workgroups
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up chose (schedule, block shape, pieces,
  *                          entries kept out of the packed stream) on stderr
  */
