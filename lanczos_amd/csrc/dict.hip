@@ -12,6 +12,7 @@
 // pattern: a hash collision cannot slip through.
 #include <hipcub/hipcub.hpp>
 
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -55,7 +56,8 @@ k_row_hash(int64_t n, const RP *__restrict__ rp, const int32_t *__restrict__ col
     }
 }
 
-// pattern[r] = index of hash[r] among the sorted distinct hashes; rep[p] = lowest row with pattern p
+// pattern[r] = index of hash[r] among the sorted distinct hashes; rep[p] = lowest row with pattern p,
+// rep[count + p] = highest one
 __global__ void __launch_bounds__(kBlock)
 k_dict_assign(int64_t n, const uint64_t *__restrict__ hash, const uint64_t *__restrict__ uniq, int count,
               uint16_t *__restrict__ pattern, int *__restrict__ rep) {
@@ -71,6 +73,7 @@ k_dict_assign(int64_t n, const uint64_t *__restrict__ hash, const uint64_t *__re
         pattern[r] = (uint16_t)lo;
         // rep only ever decreases: a plain look first keeps 16 M atomics off a handful of addresses
         if (__builtin_nontemporal_load(&rep[lo]) > (int)r) atomicMin(&rep[lo], (int)r);
+        if (__builtin_nontemporal_load(&rep[count + lo]) < (int)r) atomicMax(&rep[count + lo], (int)r);
     }
 }
 
@@ -424,7 +427,7 @@ template <int WPT>
 __global__ void __launch_bounds__(kPlanesBlock)
 k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
-                   int far_step, int cols, int planes, int seg_len, int segs, const double *__restrict__ x,
+                   int far_a, int far_b, int cols, int planes, int seg_len, int segs, const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
                    int64_t dot_lo, int64_t dot_hi) {
     constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
@@ -448,7 +451,7 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
             int e;
             if (absent) e = 3 * wlen;
             else if (off >= -halo && off <= halo) e = rot * wlen + halo + off;
-            else e = ((rot + (off < 0 ? 2 : 1)) % 3) * wlen + halo;
+            else e = ((rot + ((off < 0 || off == far_a) ? 2 : 1)) % 3) * wlen + halo;   // the plane before : the plane after
             s_idx[rot * tab + i] = e;
         }
     }
@@ -468,7 +471,13 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
         const int zb = seg * seg_len, ze = min(zb + seg_len, planes);
         dict_d2 W[WPT / 2];
         uint32_t pq;
-        auto row_of = [&](int z) -> int64_t { return ((int64_t)z * cols + col) * kDictSpan; };
+        // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
+        auto row_of = [&](int z) -> int64_t {
+            int64_t row = ((int64_t)z * cols + col) * kDictSpan;
+            if (z < 0 && far_a != INT32_MIN) row = far_a + (int64_t)col * kDictSpan;
+            if (z >= planes && far_b != INT32_MIN) row = far_b + ((int64_t)(planes - 1) * cols + col) * kDictSpan;
+            return row;
+        };
         // a plane outside the grid, or rows past the end, read as zeros (or as rows no entry refers to)
         auto load_window = [&](int z) {
             const int64_t row0 = row_of(z);
@@ -627,14 +636,15 @@ int Engine::build_dict() {
         return 0;
     }
     DC_TRY(hipMalloc(&d_pattern, sizeof(uint16_t) * n));
-    DC_TRY(hipMalloc(&d_rep, sizeof(int) * count));
+    DC_TRY(hipMalloc(&d_rep, sizeof(int) * 2 * count));
     DC_TRY(hipMemsetAsync(d_rep, 0x7F, sizeof(int) * count, stream));
+    DC_TRY(hipMemsetAsync(d_rep + count, 0xFF, sizeof(int) * count, stream));
     hipLaunchKernelGGL(k_dict_assign, dim3(rblocks), dim3(kBlock), 0, stream, n, (const uint64_t *)d_hash,
                        (const uint64_t *)d_uniq, count, d_pattern, d_rep);
     // dictionary rows as long as the longest row of the matrix (known from the 64-row spans only as
     // a bound, so measured here: the largest length among the representatives)
-    std::vector<int> rep_host((size_t)count);
-    DC_TRY(hipMemcpyAsync(rep_host.data(), d_rep, sizeof(int) * count, hipMemcpyDeviceToHost, stream));
+    std::vector<int> rep_host((size_t)2 * count);
+    DC_TRY(hipMemcpyAsync(rep_host.data(), d_rep, sizeof(int) * 2 * count, hipMemcpyDeviceToHost, stream));
     DC_TRY(hipStreamSynchronize(stream));
     int stride = 1;
     for (int p = 0; p < count; ++p) {
@@ -709,6 +719,66 @@ int Engine::build_dict() {
             }
             dict_far[dict_far_count++] = off;
         }
+    // Plane walk: one negative far offset -F with F a whole number of steps (one plane of a grid back); +F if it
+    // occurs is the plane ahead.  A row slab of a partitioned grid holds up to two more far offsets: the rows
+    // of its first plane reach the previous slab's last plane at x[r + A], those of its last plane the next
+    // slab's first plane at x[r + B] (both stored behind the slab's own entries of x).  They are taken as a plane
+    // before the first and a plane after the last, provided only rows of the first / last plane use them.
+    dict_plane_f = 0;
+    dict_plane_a = dict_plane_b = INT32_MIN;
+    {
+        std::vector<int32_t> far;
+        bool ok = true;
+        for (int p = 0; p < count && ok; ++p)
+            for (int j = 0; j < hlen[(size_t)p]; ++j) {
+                const int off = hoff[(size_t)p * stride + j], mag = off < 0 ? -off : off;
+                if (mag <= dict_halo || std::find(far.begin(), far.end(), off) != far.end()) continue;
+                far.push_back(off);
+                if (far.size() > 4) ok = false;
+            }
+        int F = 0;
+        for (int32_t o : far)
+            if (o < 0) {
+                if (F != 0 || (-(int64_t)o) % kDictSpan != 0) ok = false;
+                F = -o;
+            }
+        if (ok && F > 0 && (int64_t)F * 3 <= n) {
+            for (int32_t o : far) {
+                if (o < 0 || o == F) continue;
+                int lowest = INT32_MAX, highest = -1;  // rows that hold this offset
+                for (int p = 0; p < count; ++p)
+                    for (int j = 0; j < hlen[(size_t)p]; ++j)
+                        if (hoff[(size_t)p * stride + j] == o) {
+                            lowest = std::min(lowest, rep_host[(size_t)p]);
+                            highest = std::max(highest, rep_host[(size_t)count + p]);
+                        }
+                if (n % F != 0) ok = false;
+                else if (highest < F && dict_plane_a == INT32_MIN) dict_plane_a = o;
+                else if (lowest >= n - F && dict_plane_b == INT32_MIN) dict_plane_b = o;
+                else ok = false;
+            }
+            if (ok) dict_plane_f = F;
+        }
+        if (!dict_plane_f) dict_plane_a = dict_plane_b = INT32_MIN;
+    }
+    return 0;
+}
+
+// Which form of the dictionary SpMV this engine's dictionary runs on: 2 = plane walk, 1 = loads one step
+// ahead, 0 = loads inside the step (see the kernels above; LANCZOS_HIP_DICT_PLANES=0 / LANCZOS_HIP_DICT_AHEAD=0
+// switch the first two off for comparison).
+int Engine::dict_form() const {
+    static const bool ahead_env = !(getenv("LANCZOS_HIP_DICT_AHEAD") && atoi(getenv("LANCZOS_HIP_DICT_AHEAD")) == 0);
+    static const bool planes_env = !(getenv("LANCZOS_HIP_DICT_PLANES") && atoi(getenv("LANCZOS_HIP_DICT_PLANES")) == 0);
+    const bool fits = ahead_env && dict_patterns > 0 && dict_patterns * dict_stride <= kDictLdsEntries && n_ext > 0 &&
+                      n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31);
+    if (!fits) return 0;
+    const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
+    if (planes_env && dict_plane_f > 0 && !(dict_halo & 1) &&
+        dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536 &&
+        (chunks + dict_plane_f / kDictSpan - 1) / (dict_plane_f / kDictSpan) >= 3 && dict_plane_f / kDictSpan <= max_blocks)
+        return 2;
+    if (dict_far_count >= 0 && dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) return 1;
     return 0;
 }
 
@@ -720,20 +790,15 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     size_t win_bytes = sizeof(double) * (size_t)(kDictSpan + 2 * dict_halo);
     if (dict_patterns * dict_stride <= kDictLdsEntries)
         win_bytes += (size_t)dict_patterns * dict_stride * 12 + (size_t)dict_patterns * 4;
-    // LANCZOS_HIP_DICT_AHEAD=0 keeps the form that loads inside the step
-    static const bool ahead_env = !(getenv("LANCZOS_HIP_DICT_AHEAD") && atoi(getenv("LANCZOS_HIP_DICT_AHEAD")) == 0);
     const int wpt = (kDictSpan + 2 * dict_halo + kBlock - 1) / kBlock;
+    const int form = dict_form();
     // three-dimensional grids whose plane is a whole number of steps: the plane-walking form
-    static const bool planes_env = !(getenv("LANCZOS_HIP_DICT_PLANES") && atoi(getenv("LANCZOS_HIP_DICT_PLANES")) == 0);
-    if (planes_env && ahead_env && dict_patterns * dict_stride <= kDictLdsEntries && dict_far_count == 2 &&
-        dict_far[0] == -dict_far[1] && std::abs(dict_far[0]) % kDictSpan == 0 && !(dict_halo & 1) && n_ext > 0 &&
-        n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31) &&
-        dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
-        const int cols = std::abs(dict_far[0]) / kDictSpan;
+    if (form == 2) {
+        const int cols = dict_plane_f / kDictSpan;
         const int planes = (int)((chunks + cols - 1) / cols);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
         const int w = 2 * (((kDictSpan + 2 * dict_halo) / 2 + kPlanesBlock - 1) / kPlanesBlock);
-        if (planes >= 3) {
+        {
 #define LZ_DICT_PLANES(WPT)                                                                                          \
     do {                                                                                                             \
         if (dict_blocks == 0) {                                                                                      \
@@ -753,10 +818,11 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         hipLaunchKernelGGL((k_spmv_dict_planes<WPT>), dim3(blocks), dim3(kPlanesBlock), lds, stream, n, n_ext,       \
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
                            (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
-                           std::abs(dict_far[0]), cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials,     \
+                           (int)dict_plane_a, (int)dict_plane_b, cols, planes, dict_seg_len, dict_segs, x, xdot, y,  \
+                           d_partials,                                                                               \
                            dot_lo, dot_hi);                                                                          \
     } while (0)
-            if ((int64_t)cols * 1 <= max_blocks) {
+            {
                 if (w <= 4) LZ_DICT_PLANES(4);
                 else if (w <= 6) LZ_DICT_PLANES(6);
                 else LZ_DICT_PLANES(10);
@@ -767,9 +833,7 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
             }
         }
     }
-    if (ahead_env && dict_patterns * dict_stride <= kDictLdsEntries && dict_far_count >= 0 && n_ext > 0 &&
-        n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31) &&
-        dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) {
+    if (form == 1) {
         const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
         // one round of resident workgroups, each walking many steps
 #define LZ_DICT_AHEAD_W(WPT, WIDE, BLK)                                                                                         \

@@ -116,6 +116,8 @@ struct Engine {
     int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
     int dict_blocks = 0;       // grid of the ahead-of-time form: one round of resident workgroups
     int dict_segs = 0, dict_seg_len = 0;   // plane-walking form: segments of planes per column of steps
+    int32_t dict_plane_f = 0;  // plane-walking form: rows per plane (0: not a grid of whole-step planes)
+    int32_t dict_plane_a = 0, dict_plane_b = 0;  // a slab's offsets to the remote planes (INT32_MIN: none)
     int dict_far_count = -1;   // distinct column offsets beyond the LDS window (-1: more than two)
     int32_t dict_far[2] = {0, 0};
     // operator supplied by the caller as a host function (the reference's Matvec_General plugin,
@@ -149,6 +151,7 @@ struct Engine {
     int build_from_coo(const Coo *coo, int64_t length, int swap_row_column);
     int choose_spmv(int requested);
     int build_dict();
+    int dict_form() const;
     void free_dict();
     int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1);
     int build_panels(int bits);

@@ -393,7 +393,8 @@ int Engine::choose_spmv(int requested) {
     if (spmv_kind == LANCZOS_HIP_SPMV_MERGE)
         snprintf(spmv_name, sizeof(spmv_name), "merge%s", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
-        snprintf(spmv_name, sizeof(spmv_name), "dict%d", dict_patterns);
+        snprintf(spmv_name, sizeof(spmv_name), "dict%d%s", dict_patterns,  // p: plane walk, a: loads a step ahead
+                 dict_form() == 2 ? "p" : dict_form() == 1 ? "a" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
         snprintf(spmv_name, sizeof(spmv_name), "panel%d%s", tile_bits, rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)

@@ -52,6 +52,24 @@ def test_loopback_slabs_match_the_single_engine_and_the_oracle(gpu, reorth):
         assert rel_err(la.ritz_values(a2, b2, cmp, 4), o.eigenvalues) < 1e-10, (reorth, slabs)
 
 
+@pytest.mark.parametrize("reorth", ["full", "none"])
+def test_loopback_slabs_of_whole_planes_walk_them(gpu, reorth):
+    """64^3 cut into 2 and 4 slabs of whole planes: every slab's dictionary SpMV walks its planes, with the
+    neighbours' planes (received into the vectors' tails) as the plane before its first and after its last."""
+    a = la.synth_laplacian(3, 64)
+    v0 = la.gaussian_fill(5, 0, a.dimension)
+    steps = 30
+    a1, b1 = single(a, v0, steps, reorth)
+    for slabs in (2, 4):
+        with la.MultiEngine(a, steps + 1, slabs, reorth=reorth, loopback=True) as m:
+            assert m.info()["halo"] == 1
+            assert all(m.slab_spmv_name(s).startswith("dict") and m.slab_spmv_name(s).endswith("p") for s in range(slabs))
+            m.set_start(v0)
+            a2, b2 = m.run(steps)
+        cmp = 25 if reorth == "none" else steps
+        assert rel_err(a2[:cmp], a1[:cmp]) < 1e-11 and rel_err(b2[:cmp], b1[:cmp]) < 1e-11, (reorth, slabs)
+
+
 @pytest.mark.parametrize("spmv", ["panel", "merge"])
 def test_loopback_slabs_on_the_gather_bound_forms(gpu, spmv):
     """Slabs whose columns reach all over the vector (all-gather layout), on the tiled and the

@@ -129,7 +129,7 @@ def test_spmv_zero_matrix_and_auto_kernel(gpu, monkeypatch):
         want = oracle.matvec_crs(r.row_head_indexes, r.column_index, r.values, x)
         assert np.all(np.abs(e.spmv(x) - want) <= spmv_tolerance(r, x))
     with la.Engine(la.synth_laplacian(3, 16), 3) as e:
-        assert e.spmv_name == "dict27"           # a cube's rows: interior, 6 faces, 12 edges, 8 corners
+        assert e.spmv_name == "dict27a"          # a cube's rows: interior, 6 faces, 12 edges, 8 corners; N^2 <= 2048: no far entries
     monkeypatch.setenv("LANCZOS_HIP_NO_DICT", "1")
     with la.Engine(la.synth_laplacian(3, 16), 3) as e:
         assert e.spmv_name == "rows64"           # stencil: neighbouring rows hold neighbouring columns
@@ -178,17 +178,18 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
 
 def test_dictionary_spmv_forms_on_grids(gpu):
     """The dictionary SpMV picks its form from the grid: planes that are a whole number of 1024-row steps
-    are walked plane by plane (N a multiple of 32: one column of steps at 32^3, four at 64^3, nine at 96^3,
-    segments of planes), other even plane sizes take 16-byte loads, odd ones (N = 33, 45: pairs of doubles
-    would straddle the start of x) 8-byte loads, and small grids (N^2 <= 2048) have no far entries at
-    all.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
+    are walked plane by plane (N a multiple of 32 beyond the window's reach: four columns of steps at 64^3,
+    nine at 96^3, segments of planes), other even plane sizes take 16-byte loads (N = 46), odd ones (N = 47:
+    pairs of doubles would straddle the start of x) 8-byte loads, and small grids (N^2 <= 2048: N = 12, 32,
+    33, 40, 45) have no far entries at all.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
     odd vector lengths too, and the alpha partial that goes with them."""
-    for N in (12, 32, 33, 40, 45, 46, 64, 96):
+    for N in (12, 32, 33, 40, 45, 46, 47, 64, 96):
         a = la.synth_laplacian(3, N)
         rng = np.random.default_rng(N)
         x = rng.standard_normal(a.dimension)
         with la.Engine(a, 4, spmv="dict") as e:
-            assert e.spmv_name.startswith("dict")
+            # N = 45: a window of 1024 + 2 * 2026 doubles plus the other regions is beyond 64 KiB of LDS: the first form
+            assert e.spmv_name == ("dict27p" if N in (64, 96) else "dict27" if N == 45 else "dict27a"), e.spmv_name
             y = e.spmv(x)
             e.set_start(x)
             alpha, _ = e.run(2)
@@ -208,6 +209,7 @@ def test_dictionary_spmv_forms_on_grids(gpu):
         b = la.CrsMatrix(a.values[:h[-1]][keep], a.column_index[:h[-1]][keep], head)
         x = np.random.default_rng(n).standard_normal(n)
         with la.Engine(b, 3, spmv="dict") as e:
+            assert e.spmv_name.endswith("p")
             y = e.spmv(x)
         with la.Engine(b, 3, spmv="rows") as e:
             assert e.spmv(x).tobytes() == y.tobytes(), n
@@ -237,7 +239,7 @@ def test_dictionary_spmv_on_repeating_rows(gpu):
     b = la.CrsMatrix(vals, a.column_index, a.row_head_indexes)
     x = np.random.default_rng(2).standard_normal(b.dimension)
     with la.Engine(b, 3, spmv="dict") as e:
-        assert int(e.spmv_name[4:]) == 9 + 3
+        assert int(e.spmv_name[4:].rstrip("ap")) == 9 + 3
         assert np.all(np.abs(e.spmv(x) - oracle.matvec_crs(b.row_head_indexes, b.column_index, b.values, x))
                       <= spmv_tolerance(b, x))
     with pytest.raises(la.LanczosHipError, match="dictionary SpMV needs rows"):
@@ -289,7 +291,7 @@ def test_panel_spmv_on_random_sparsity(gpu, monkeypatch):
     assert np.all(np.abs(yg - oracle.matvec_crs(big.row_head_indexes, big.column_index, big.values, xg))
                   <= spmv_tolerance(big, xg))
     with la.Engine(la.synth_laplacian(3, 64), 3) as e:
-        assert e.spmv_name == "dict27"
+        assert e.spmv_name == "dict27p"          # planes of 4096 rows: walked plane by plane
 
 
 @pytest.mark.parametrize("log2n", [24, 25])
