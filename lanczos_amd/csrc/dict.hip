@@ -409,9 +409,9 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
 }
 
 // Grids in three dimensions: the two far offsets are -F and +F (one plane of the grid back and ahead).
-// When F is a multiple of the step's rows, a workgroup that walks from plane to plane -- rows
-// [c, c + kDictSpan) of plane z, then the same rows of plane z + 1 -- finds its far entries in the
-// windows of the step before and the step after.  Three windows stay in LDS (a ring), every step loads
+// A workgroup that walks from plane to plane -- rows [c, c + kDictSpan) of plane z, then the same rows
+// of plane z + 1, F rows further -- finds its far entries in the windows of the step before and the
+// step after.  Three windows stay in LDS (a ring), every step loads
 // one, and x is fetched 1.5 times per product (the windows' halos) in place of 3.5 times; the form above
 // is bound by the rate of L1 misses, which this one halves.  The planes are cut into segments so that
 // every CU has its workgroups; a segment loads one plane before and one after its own.  Index tables
@@ -427,7 +427,8 @@ template <int WPT>
 __global__ void __launch_bounds__(kPlanesBlock)
 k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
-                   int far_a, int far_b, int cols, int planes, int seg_len, int segs, const double *__restrict__ x,
+                   int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
+                   const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
                    int64_t dot_lo, int64_t dot_hi) {
     constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
@@ -472,10 +473,12 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
         dict_d2 W[WPT / 2];
         uint32_t pq;
         // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
+        // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
+        const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
         auto row_of = [&](int z) -> int64_t {
-            int64_t row = ((int64_t)z * cols + col) * kDictSpan;
+            int64_t row = (int64_t)z * plane_rows + (int64_t)col * kDictSpan;
             if (z < 0 && far_a != INT32_MIN) row = far_a + (int64_t)col * kDictSpan;
-            if (z >= planes && far_b != INT32_MIN) row = far_b + ((int64_t)(planes - 1) * cols + col) * kDictSpan;
+            if (z >= planes && far_b != INT32_MIN) row = far_b + (int64_t)(planes - 1) * plane_rows + (int64_t)col * kDictSpan;
             return row;
         };
         // a plane outside the grid, or rows past the end, read as zeros (or as rows no entry refers to)
@@ -521,7 +524,7 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
 #pragma unroll
             for (int u = 0; u < ROWS; ++u) {
                 const int64_t r = row0 + u * BLOCK + tid;
-                if (r < n) {
+                if (r < n && u * BLOCK + tid < lim) {
                     double xd = win[ROT * wlen + halo + u * BLOCK + tid];
                     if (xdot != x) xd = xdot[r];
                     const double t = xd * sum[u];
@@ -534,9 +537,10 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
             const double mine = odd ? sum[1] : sum[0];
             const double got = __shfl_xor(odd ? sum[0] : sum[1], 1);
             const dict_d2 s2 = odd ? dict_d2{got, mine} : dict_d2{mine, got};
-            const int64_t r2 = row0 + (odd ? BLOCK : 0) + (tid & ~1);
-            if (r2 + 1 < n) __builtin_nontemporal_store(s2, reinterpret_cast<dict_d2 *>(y + r2));
-            else if (r2 < n) __builtin_nontemporal_store(s2.x, y + r2);
+            const int l2 = (odd ? BLOCK : 0) + (tid & ~1);
+            const int64_t r2 = row0 + l2;
+            if (r2 + 1 < n && l2 + 1 < lim) __builtin_nontemporal_store(s2, reinterpret_cast<dict_d2 *>(y + r2));
+            else if (r2 < n && l2 < lim) __builtin_nontemporal_store(s2.x, y + r2);
         };
         // the planes before and of the first step go to ring slots 0 and 1, the one after it waits in registers
         load_window(zb - 1);
@@ -719,7 +723,7 @@ int Engine::build_dict() {
             }
             dict_far[dict_far_count++] = off;
         }
-    // Plane walk: one negative far offset -F with F a whole number of steps (one plane of a grid back); +F if it
+    // Plane walk: one negative far offset -F, F even (one plane of a grid back); +F if it
     // occurs is the plane ahead.  A row slab of a partitioned grid holds up to two more far offsets: the rows
     // of its first plane reach the previous slab's last plane at x[r + A], those of its last plane the next
     // slab's first plane at x[r + B] (both stored behind the slab's own entries of x).  They are taken as a plane
@@ -739,7 +743,7 @@ int Engine::build_dict() {
         int F = 0;
         for (int32_t o : far)
             if (o < 0) {
-                if (F != 0 || (-(int64_t)o) % kDictSpan != 0) ok = false;
+                if (F != 0 || ((-(int64_t)o) & 1)) ok = false;   // even: 16-byte loads must not straddle the start of x
                 F = -o;
             }
         if (ok && F > 0 && (int64_t)F * 3 <= n) {
@@ -773,10 +777,9 @@ int Engine::dict_form() const {
     const bool fits = ahead_env && dict_patterns > 0 && dict_patterns * dict_stride <= kDictLdsEntries && n_ext > 0 &&
                       n_ext < ((int64_t)1 << 29) && n < ((int64_t)1 << 31);
     if (!fits) return 0;
-    const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
     if (planes_env && dict_plane_f > 0 && !(dict_halo & 1) &&
         dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536 &&
-        (chunks + dict_plane_f / kDictSpan - 1) / (dict_plane_f / kDictSpan) >= 3 && dict_plane_f / kDictSpan <= max_blocks)
+        (n + dict_plane_f - 1) / dict_plane_f >= 3 && (dict_plane_f + kDictSpan - 1) / kDictSpan <= max_blocks)
         return 2;
     if (dict_far_count >= 0 && dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride) <= 65536) return 1;
     return 0;
@@ -794,8 +797,8 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     const int form = dict_form();
     // three-dimensional grids whose plane is a whole number of steps: the plane-walking form
     if (form == 2) {
-        const int cols = dict_plane_f / kDictSpan;
-        const int planes = (int)((chunks + cols - 1) / cols);
+        const int cols = (dict_plane_f + kDictSpan - 1) / kDictSpan;
+        const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
         const int w = 2 * (((kDictSpan + 2 * dict_halo) / 2 + kPlanesBlock - 1) / kPlanesBlock);
         {
@@ -818,8 +821,8 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         hipLaunchKernelGGL((k_spmv_dict_planes<WPT>), dim3(blocks), dim3(kPlanesBlock), lds, stream, n, n_ext,       \
                            (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
                            (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
-                           (int)dict_plane_a, (int)dict_plane_b, cols, planes, dict_seg_len, dict_segs, x, xdot, y,  \
-                           d_partials,                                                                               \
+                           (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f, cols, planes, dict_seg_len,      \
+                           dict_segs, x, xdot, y, d_partials,                                                        \
                            dot_lo, dot_hi);                                                                          \
     } while (0)
             {

@@ -177,19 +177,19 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
 
 
 def test_dictionary_spmv_forms_on_grids(gpu):
-    """The dictionary SpMV picks its form from the grid: planes that are a whole number of 1024-row steps
-    are walked plane by plane (N a multiple of 32 beyond the window's reach: four columns of steps at 64^3,
-    nine at 96^3, segments of planes), other even plane sizes take 16-byte loads (N = 46), odd ones (N = 47:
-    pairs of doubles would straddle the start of x) 8-byte loads, and small grids (N^2 <= 2048: N = 12, 32,
-    33, 40, 45) have no far entries at all.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
+    """The dictionary SpMV picks its form from the grid: an even plane beyond the window's reach is walked
+    plane by plane (N = 46: three columns of steps, the last of 68 rows; 64 and 96: whole steps; 100: ten
+    columns, segments of planes), odd ones (N = 47: pairs of doubles would straddle the start of x) load one
+    step ahead with 8-byte loads, small grids (N^2 <= 2048: N = 12, 32, 33, 40) have no far entries at all,
+    and N = 45 (a window of 1024 + 2 * 2026 doubles plus the other regions is beyond 64 KiB of LDS) keeps the
+    first form.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
     odd vector lengths too, and the alpha partial that goes with them."""
-    for N in (12, 32, 33, 40, 45, 46, 47, 64, 96):
+    for N in (12, 32, 33, 40, 45, 46, 47, 64, 96, 100):
         a = la.synth_laplacian(3, N)
         rng = np.random.default_rng(N)
         x = rng.standard_normal(a.dimension)
         with la.Engine(a, 4, spmv="dict") as e:
-            # N = 45: a window of 1024 + 2 * 2026 doubles plus the other regions is beyond 64 KiB of LDS: the first form
-            assert e.spmv_name == ("dict27p" if N in (64, 96) else "dict27" if N == 45 else "dict27a"), e.spmv_name
+            assert e.spmv_name == ("dict27p" if N in (46, 64, 96, 100) else "dict27" if N == 45 else "dict27a"), e.spmv_name
             y = e.spmv(x)
             e.set_start(x)
             alpha, _ = e.run(2)
