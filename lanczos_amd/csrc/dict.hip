@@ -452,7 +452,10 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
             int e;
             if (absent) e = 3 * wlen;
             else if (off >= -halo && off <= halo) e = rot * wlen + halo + off;
-            else e = ((rot + ((off < 0 || off == far_a) ? 2 : 1)) % 3) * wlen + halo;   // the plane before : the plane after
+            else if (off == far_a) e = ((rot + 2) % 3) * wlen + halo;                       // a slab's remote plane before
+            else if (off == far_b) e = ((rot + 1) % 3) * wlen + halo;                       // ... and after
+            else if (off < 0) e = ((rot + 2) % 3) * wlen + halo + (off + plane_rows);       // around -F: the window F back
+            else e = ((rot + 1) % 3) * wlen + halo + (off - plane_rows);                    // around +F: the window F ahead
             s_idx[rot * tab + i] = e;
         }
     }
@@ -723,32 +726,54 @@ int Engine::build_dict() {
             }
             dict_far[dict_far_count++] = off;
         }
-    // Plane walk: one negative far offset -F, F even (one plane of a grid back); +F if it
-    // occurs is the plane ahead.  A row slab of a partitioned grid holds up to two more far offsets: the rows
-    // of its first plane reach the previous slab's last plane at x[r + A], those of its last plane the next
-    // slab's first plane at x[r + B] (both stored behind the slab's own entries of x).  They are taken as a plane
-    // before the first and a plane after the last, provided only rows of the first / last plane use them.
-    dict_plane_f = 0;
-    dict_plane_a = dict_plane_b = INT32_MIN;
-    {
+    // Plane walk: the far offsets lie within the window's halo of -F and +F for some even F (a 7-point grid
+    // has -F and +F themselves, a 27-point one nine offsets around each; for an odd plane size F is the
+    // next even number): x[r + o] is then found in the window of the rows F back or F ahead.  A row slab
+    // of a partitioned 7-point grid holds up to two more far offsets: the rows of its first plane reach the
+    // previous slab's last plane at x[r + A], those of its last plane the next slab's first plane at
+    // x[r + B] (both stored behind the slab's own entries of x).  They are taken as a plane before the first
+    // and a plane after the last, provided only rows of the first / last plane use them.
+    // (an odd plane of a 27-point grid needs a halo one or two entries wider than the near offsets ask for)
+    auto plan_planes = [&](int halo_w) -> int {   // returns the halo the far offsets would need, 0 if none will do
+        dict_plane_f = 0;
+        dict_plane_a = dict_plane_b = INT32_MIN;
+        int need = 0;
         std::vector<int32_t> far;
         bool ok = true;
         for (int p = 0; p < count && ok; ++p)
             for (int j = 0; j < hlen[(size_t)p]; ++j) {
                 const int off = hoff[(size_t)p * stride + j], mag = off < 0 ? -off : off;
-                if (mag <= dict_halo || std::find(far.begin(), far.end(), off) != far.end()) continue;
+                if (mag <= halo_w || std::find(far.begin(), far.end(), off) != far.end()) continue;
                 far.push_back(off);
-                if (far.size() > 4) ok = false;
+                if (far.size() > 64) ok = false;
             }
-        int F = 0;
+        int64_t lo = 0, hi = 0;
+        int negatives = 0;
         for (int32_t o : far)
             if (o < 0) {
-                if (F != 0 || ((-(int64_t)o) & 1)) ok = false;   // even: 16-byte loads must not straddle the start of x
-                F = -o;
+                lo = negatives ? std::min<int64_t>(lo, o) : o;
+                hi = negatives ? std::max<int64_t>(hi, o) : o;
+                ++negatives;
             }
-        if (ok && F > 0 && (int64_t)F * 3 <= n) {
+        const int64_t F = negatives ? ((-(lo + hi) / 2) + 1) & ~(int64_t)1 : 0;
+        if (ok && F > 0 && F * 3 <= n && F < INT32_MAX) {
+            std::vector<int32_t> others;
+            bool exact = negatives == 1 && -lo == F;
             for (int32_t o : far) {
-                if (o < 0 || o == F) continue;
+                if (o < 0) {
+                    need = std::max<int>(need, (int)std::min<int64_t>(std::abs((int64_t)o + F), INT32_MAX / 2));
+                    if (std::abs((int64_t)o + F) > halo_w) ok = false;
+                } else if (std::abs((int64_t)o - F) <= halo_w + 2) {
+                    need = std::max<int>(need, (int)std::abs((int64_t)o - F));
+                    if (std::abs((int64_t)o - F) > halo_w) ok = false;
+                    exact = exact && o == F;
+                } else {
+                    others.push_back(o);
+                }
+            }
+            if (!others.empty() && (!exact || others.size() > 2 || n % F != 0)) ok = false;
+            for (size_t q = 0; q < others.size() && ok; ++q) {
+                const int32_t o = others[q];
                 int lowest = INT32_MAX, highest = -1;  // rows that hold this offset
                 for (int p = 0; p < count; ++p)
                     for (int j = 0; j < hlen[(size_t)p]; ++j)
@@ -756,14 +781,21 @@ int Engine::build_dict() {
                             lowest = std::min(lowest, rep_host[(size_t)p]);
                             highest = std::max(highest, rep_host[(size_t)count + p]);
                         }
-                if (n % F != 0) ok = false;
-                else if (highest < F && dict_plane_a == INT32_MIN) dict_plane_a = o;
+                if (highest < F && dict_plane_a == INT32_MIN) dict_plane_a = o;
                 else if (lowest >= n - F && dict_plane_b == INT32_MIN) dict_plane_b = o;
                 else ok = false;
             }
-            if (ok) dict_plane_f = F;
+            if (ok) dict_plane_f = (int32_t)F;
         }
         if (!dict_plane_f) dict_plane_a = dict_plane_b = INT32_MIN;
+        return dict_plane_f ? 0 : need;
+    };
+    const int need = plan_planes(dict_halo);
+    if (!dict_plane_f && need > dict_halo && need <= dict_halo + 2 && ((need + 1) & ~1) <= kDictMaxHalo) {
+        const int keep = dict_halo;
+        dict_halo = (need + 1) & ~1;
+        plan_planes(dict_halo);
+        if (!dict_plane_f) dict_halo = keep;
     }
     return 0;
 }

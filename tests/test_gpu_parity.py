@@ -179,8 +179,8 @@ def test_rows_spmv_on_short_irregular_rows_and_its_limit(gpu):
 def test_dictionary_spmv_forms_on_grids(gpu):
     """The dictionary SpMV picks its form from the grid: an even plane beyond the window's reach is walked
     plane by plane (N = 46: three columns of steps, the last of 68 rows; 64 and 96: whole steps; 100: ten
-    columns, segments of planes), odd ones (N = 47: pairs of doubles would straddle the start of x) load one
-    step ahead with 8-byte loads, small grids (N^2 <= 2048: N = 12, 32, 33, 40) have no far entries at all,
+    columns, segments of planes; N = 47: an odd plane is walked in steps of the next even number of rows, the
+    far entries one slot off the middle of the neighbouring windows), small grids (N^2 <= 2048: N = 12, 32, 33, 40) have no far entries at all,
     and N = 45 (a window of 1024 + 2 * 2026 doubles plus the other regions is beyond 64 KiB of LDS) keeps the
     first form.  Every form gives the bits of the row-wise kernel (entries in CRS order, src/crs.c:172-175), on
     odd vector lengths too, and the alpha partial that goes with them."""
@@ -189,7 +189,7 @@ def test_dictionary_spmv_forms_on_grids(gpu):
         rng = np.random.default_rng(N)
         x = rng.standard_normal(a.dimension)
         with la.Engine(a, 4, spmv="dict") as e:
-            assert e.spmv_name == ("dict27p" if N in (46, 64, 96, 100) else "dict27" if N == 45 else "dict27a"), e.spmv_name
+            assert e.spmv_name == ("dict27p" if N in (46, 47, 64, 96, 100) else "dict27" if N == 45 else "dict27a"), e.spmv_name
             y = e.spmv(x)
             e.set_start(x)
             alpha, _ = e.run(2)
@@ -200,6 +200,20 @@ def test_dictionary_spmv_forms_on_grids(gpu):
         assert rel_err(alpha, alpha_rows) < 1e-13, N
         want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
         assert np.all(np.abs(y - want) <= spmv_tolerance(a, x)), N
+    # a 27-point stencil (nine far entries around each of -N^2 and +N^2: all inside the halos of the neighbouring
+    # planes' windows), even and odd N; LANCZOS_HIP_DICT_PLANES=0 would leave it to the first form
+    import scipy.sparse as sp
+    for N in (48, 53):
+        t = sp.diags([0.5, 2.0, -1.5], [-1, 0, 1], shape=(N, N))
+        m = sp.kron(sp.kron(t, t), t).tocsr()
+        m.sort_indices()
+        b = la.CrsMatrix(m.data.astype(np.float64), m.indices.astype(np.int64), m.indptr.astype(np.int64))
+        x = np.random.default_rng(N).standard_normal(b.dimension)
+        with la.Engine(b, 3, spmv="dict") as e:
+            assert e.spmv_name == "dict27p", e.spmv_name
+            y = e.spmv(x)
+        want = oracle.matvec_crs(b.row_head_indexes, b.column_index, b.values, x)   # (27 entries per row: no row-wise form)
+        assert np.all(np.abs(y - want) <= spmv_tolerance(b, x)), N
     # a grid cut off in the middle of a plane (the last plane is partial), and one row fewer (odd length)
     a = la.synth_laplacian(3, 64)
     for n in (64 * 64 * 40 + 1500, 64 * 64 * 40 + 1501):
