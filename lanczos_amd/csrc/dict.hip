@@ -269,7 +269,7 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
         else if (off >= -halo && off <= halo) e = halo + off;                    // in the window
         else e = wlen + (off == far0 ? 0 : kDictSpan);                           // in a far region
         s_idx[i] = e;
-        s_val[i] = absent ? 0.0 : dval[i];
+        s_val[i] = absent ? -0.0 : dval[i];   // (-0.0) x (+0.0) added to a sum leaves it as it is, signed zeros included
     }
     for (int i = tid; i < kDictSpan; i += BLOCK) s_zero[i] = 0.0;
     const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
@@ -445,7 +445,7 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ patter
     for (int i = tid; i < tab; i += BLOCK) {
         const int off = doff[i];
         const bool absent = i % stride >= dlen[i / stride];
-        s_val[i] = absent ? 0.0 : dval[i];
+        s_val[i] = absent ? -0.0 : dval[i];   // (-0.0) x (+0.0) added to a sum leaves it as it is, signed zeros included
 #pragma unroll
         for (int rot = 0; rot < 3; ++rot) {
             // ring slot `rot` holds this step's window, the slot before it the previous plane's, the slot after it the next one's
