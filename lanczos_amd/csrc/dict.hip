@@ -817,109 +817,89 @@ int Engine::dict_form() const {
     return 0;
 }
 
+// The instantiations of a form share one signature, so the choice among them is a function pointer.
+using DictAheadKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, int, const int32_t *, const int32_t *,
+                                 const double *, int, int, const double *, const double *, double *, double *, int64_t,
+                                 int64_t);
+using DictPlanesKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, int, const int32_t *, const int32_t *,
+                                  const double *, int, int, int, int, int, int, int, const double *, const double *,
+                                  double *, double *, int64_t, int64_t);
+
+// window doubles per thread (even: loaded in pairs) for a window of `wlen` doubles and `block` threads
+static int dict_window_per_thread(int wlen, int block) { return 2 * ((wlen / 2 + block - 1) / block); }
+
+template <bool WIDE>
+static DictAheadKernel dict_ahead_kernel(int block, int w) {
+    if (block == 512)
+        return w <= 4 ? k_spmv_dict_ahead<4, WIDE, 512> : w <= 6 ? k_spmv_dict_ahead<6, WIDE, 512> : k_spmv_dict_ahead<10, WIDE, 512>;
+    return w <= 6    ? k_spmv_dict_ahead<6, WIDE, 256>
+           : w <= 8  ? k_spmv_dict_ahead<8, WIDE, 256>
+           : w <= 12 ? k_spmv_dict_ahead<12, WIDE, 256>
+                     : k_spmv_dict_ahead<20, WIDE, 256>;
+}
+
+// workgroups of `kernel` that fit a CU at once
+template <typename K>
+static int dict_resident(K kernel, int block, size_t lds) {
+    int occ = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel, block, lds) != hipSuccess || occ < 1) occ = 1;
+    return occ;
+}
+
 int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo, int64_t dot_hi) {
     if (dot_hi < 0) dot_hi = n;
-    const int64_t chunks = (n + kBlock * kDictRows - 1) / (kBlock * kDictRows);
-    int blocks = (int)std::min<int64_t>(max_blocks, (chunks + 7) / 8 * 8);
-    *nparts = blocks;
-    size_t win_bytes = sizeof(double) * (size_t)(kDictSpan + 2 * dict_halo);
-    if (dict_patterns * dict_stride <= kDictLdsEntries)
-        win_bytes += (size_t)dict_patterns * dict_stride * 12 + (size_t)dict_patterns * 4;
-    const int wpt = (kDictSpan + 2 * dict_halo + kBlock - 1) / kBlock;
+    const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
+    const int wlen = kDictSpan + 2 * dict_halo;
+    const uint16_t *pat = (const uint16_t *)d_pattern;
+    const int32_t *dl = (const int32_t *)d_dlen, *dof = (const int32_t *)d_doff;
+    const double *dv = (const double *)d_dval;
     const int form = dict_form();
-    // three-dimensional grids whose plane is a whole number of steps: the plane-walking form
     if (form == 2) {
+        // a grid in three dimensions, walked plane by plane; the grid is one round of resident workgroups, the
+        // planes cut into as many segments as that takes (at least three planes each)
         const int cols = (dict_plane_f + kDictSpan - 1) / kDictSpan;
         const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
-        const int w = 2 * (((kDictSpan + 2 * dict_halo) / 2 + kPlanesBlock - 1) / kPlanesBlock);
-        {
-#define LZ_DICT_PLANES(WPT)                                                                                          \
-    do {                                                                                                             \
-        if (dict_blocks == 0) {                                                                                      \
-            int occ = 0;                                                                                             \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_planes<WPT>, kPlanesBlock, lds) !=    \
-                    hipSuccess || occ < 1)                                                                           \
-                occ = 1;                                                                                             \
-            const int64_t want = std::min<int64_t>((int64_t)cus * occ, max_blocks);                                  \
-            dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));                       \
-            dict_seg_len = (planes + dict_segs - 1) / dict_segs;                                                     \
-            dict_segs = (planes + dict_seg_len - 1) / dict_seg_len;                                                  \
-            const int64_t per_xcd = ((int64_t)cols * dict_segs + 7) / 8;                                             \
-            dict_blocks = (int)(per_xcd * 8);                                                                        \
-        }                                                                                                            \
-        blocks = dict_blocks;                                                                                        \
-        *nparts = blocks;                                                                                            \
-        hipLaunchKernelGGL((k_spmv_dict_planes<WPT>), dim3(blocks), dim3(kPlanesBlock), lds, stream, n, n_ext,       \
-                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
-                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
-                           (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f, cols, planes, dict_seg_len,      \
-                           dict_segs, x, xdot, y, d_partials,                                                        \
-                           dot_lo, dot_hi);                                                                          \
-    } while (0)
-            {
-                if (w <= 4) LZ_DICT_PLANES(4);
-                else if (w <= 6) LZ_DICT_PLANES(6);
-                else LZ_DICT_PLANES(10);
-#undef LZ_DICT_PLANES
-                const hipError_t stp = hipGetLastError();
-                if (stp != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(stp));
-                return 0;
-            }
+        const int w = dict_window_per_thread(wlen, kPlanesBlock);
+        const DictPlanesKernel kernel = w <= 4 ? k_spmv_dict_planes<4> : w <= 6 ? k_spmv_dict_planes<6> : k_spmv_dict_planes<10>;
+        if (dict_blocks == 0) {
+            const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
+            dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
+            dict_seg_len = (planes + dict_segs - 1) / dict_segs;
+            dict_segs = (planes + dict_seg_len - 1) / dict_seg_len;
+            dict_blocks = (int)(((int64_t)cols * dict_segs + 7) / 8 * 8);
         }
-    }
-    if (form == 1) {
-        const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
-        // one round of resident workgroups, each walking many steps
-#define LZ_DICT_AHEAD_W(WPT, WIDE, BLK)                                                                                         \
-    do {                                                                                                             \
-        if (dict_blocks == 0) {                                                                                      \
-            int occ = 0;                                                                                             \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmv_dict_ahead<WPT, WIDE, BLK>, BLK, lds) !=           \
-                    hipSuccess || occ < 1)                                                                           \
-                occ = 1;                                                                                             \
-            dict_blocks =                                                                                            \
-                (int)std::min<int64_t>(std::min<int64_t>((int64_t)cus * occ, max_blocks), (chunks + 7) / 8 * 8);     \
-        }                                                                                                            \
-        blocks = dict_blocks;                                                                                        \
-        *nparts = blocks;                                                                                            \
-        hipLaunchKernelGGL((k_spmv_dict_ahead<WPT, WIDE, BLK>), dim3(blocks), dim3(BLK), lds, stream, n, n_ext,              \
-                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,                       \
-                           (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval,                 \
-                           (int)dict_far[0], (int)dict_far[1], x, xdot, y, d_partials, dot_lo, dot_hi);              \
-    } while (0)
-        // 16-byte loads when no pair of doubles can straddle the start of x (LANCZOS_HIP_DICT_WIDE=0: never)
+        *nparts = dict_blocks;
+        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, pat, dict_patterns,
+                           dict_stride, dict_halo, dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
+                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);
+    } else if (form == 1) {
+        // loads one step ahead; 16-byte loads when no pair of doubles can straddle the start of x
+        // (LANCZOS_HIP_DICT_WIDE=0: never); 512 threads, two rows per thread (LANCZOS_HIP_DICT_BLOCK=256: four)
         static const bool wide_env = !(getenv("LANCZOS_HIP_DICT_WIDE") && atoi(getenv("LANCZOS_HIP_DICT_WIDE")) == 0);
+        static const int block = getenv("LANCZOS_HIP_DICT_BLOCK") && atoi(getenv("LANCZOS_HIP_DICT_BLOCK")) == 256 ? 256 : 512;
         const bool wide = wide_env && !(dict_far[0] & 1) && !(dict_far[1] & 1) && !(dict_halo & 1);
-#define LZ_DICT_AHEAD(WPT, BLK)                    \
-    do {                                           \
-        if (wide) LZ_DICT_AHEAD_W(WPT, true, BLK); \
-        else LZ_DICT_AHEAD_W(WPT, false, BLK);     \
-    } while (0)
-        // 512 threads (two rows per thread): twice the wavefronts per CU at the same LDS footprint
-        static const int blk_env = getenv("LANCZOS_HIP_DICT_BLOCK") ? atoi(getenv("LANCZOS_HIP_DICT_BLOCK")) : 512;
-        const int wlen = kDictSpan + 2 * dict_halo;
-        if (blk_env == 512) {
-            const int w = 2 * ((wlen / 2 + 511) / 512);
-            if (w <= 4) LZ_DICT_AHEAD(4, 512);
-            else if (w <= 6) LZ_DICT_AHEAD(6, 512);
-            else LZ_DICT_AHEAD(10, 512);
-        } else {
-            if (wpt <= 6) LZ_DICT_AHEAD(6, 256);
-            else if (wpt <= 8) LZ_DICT_AHEAD(8, 256);
-            else if (wpt <= 12) LZ_DICT_AHEAD(12, 256);
-            else LZ_DICT_AHEAD(20, 256);
-        }
-#undef LZ_DICT_AHEAD
-#undef LZ_DICT_AHEAD_W
-    } else if (dict_patterns * dict_stride <= kDictLdsEntries)
-        hipLaunchKernelGGL((k_spmv_dict<true>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
-                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
-                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials, dot_lo, dot_hi);
-    else
-        hipLaunchKernelGGL((k_spmv_dict<false>), dim3(blocks), dim3(kBlock), win_bytes, stream, n, n_ext,
-                           (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo, (const int32_t *)d_dlen,
-                           (const int32_t *)d_doff, (const double *)d_dval, x, xdot, y, d_partials, dot_lo, dot_hi);
+        const size_t lds = dict_ahead_lds_bytes(dict_halo, dict_patterns, dict_stride);
+        const int w = dict_window_per_thread(wlen, block);
+        const DictAheadKernel kernel = wide ? dict_ahead_kernel<true>(block, w) : dict_ahead_kernel<false>(block, w);
+        if (dict_blocks == 0)
+            dict_blocks = (int)std::min<int64_t>(
+                std::min<int64_t>((int64_t)cus * dict_resident(kernel, block, lds), max_blocks), (chunks + 7) / 8 * 8);
+        *nparts = dict_blocks;
+        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(block), lds, stream, n, n_ext, pat, dict_patterns, dict_stride,
+                           dict_halo, dl, dof, dv, (int)dict_far[0], (int)dict_far[1], x, xdot, y, d_partials, dot_lo,
+                           dot_hi);
+    } else {
+        // loads inside the step; the dictionary in LDS when it fits
+        const int blocks = (int)std::min<int64_t>(max_blocks, (chunks + 7) / 8 * 8);
+        *nparts = blocks;
+        const bool in_lds = dict_patterns * dict_stride <= kDictLdsEntries;
+        const size_t lds = sizeof(double) * (size_t)wlen +
+                           (in_lds ? (size_t)dict_patterns * dict_stride * 12 + (size_t)dict_patterns * 4 : 0);
+        hipLaunchKernelGGL(in_lds ? k_spmv_dict<true> : k_spmv_dict<false>, dim3(blocks), dim3(kBlock), lds, stream, n,
+                           n_ext, pat, dict_patterns, dict_stride, dict_halo, dl, dof, dv, x, xdot, y, d_partials, dot_lo,
+                           dot_hi);
+    }
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;
