@@ -66,3 +66,51 @@ def test_random_symmetric_matrices_follow_the_oracle(gpu, reorth, oracle_mode, t
         scale = np.abs(o.alpha).max() + np.abs(o.beta).max()
         assert np.max(np.abs(alpha - o.alpha[:steps])) < tol * scale, (reorth, n)
         assert rel_err(beta, o.beta[:steps]) < tol, (reorth, n)
+
+
+def test_random_stencils_through_the_dictionary_forms(gpu):
+    """Banded matrices with constant diagonals (rows repeat as patterns) at random offsets: a few within the
+    window's reach, a few far ones placed around one or two planes' distance, symmetric or one-sided, even or
+    odd, sizes that end inside a plane.  Whatever form the dictionary SpMV picks for them (plane walk, loads
+    one step ahead with 16- or 8-byte loads, loads inside the step), its product has the bits of the row-wise
+    kernel where that one applies (up to seven entries per row) and stays within rounding of the CPU
+    checker's otherwise; the alpha partial is checked through one Lanczos step."""
+    import numpy as np
+    import scipy.sparse as sp
+
+    import lanczos_amd as la
+    import oracle
+
+    def spmv_tolerance(a, x):
+        absrow = oracle.matvec_crs(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x))
+        return (int(np.diff(a.row_head_indexes).max()) + 4) * np.finfo(float).eps * absrow + 1e-300
+
+    rng = np.random.default_rng(int(os.environ.get("LANCZOS_FUZZ_STENCIL_SEED", "2024")))
+    seen = set()
+    for case in range(int(os.environ.get("LANCZOS_FUZZ_STENCILS", "40"))):
+        n = int(rng.integers(30_000, 260_000))
+        near = set(int(o) for o in rng.choice([-3, -2, -1, 1, 2, 3, -17, 17, -130, 130, -600, 600, -2000, 2000],
+                                               size=int(rng.integers(1, 4)), replace=False))
+        plane = int(rng.choice([2100, 2101, 4096, 5000, 6561, 9999, 10240]))
+        kind = int(rng.integers(0, 5))
+        far = {0: {-plane, plane}, 1: {-plane}, 2: {plane}, 3: {-plane - 1, -plane, plane, plane + 2},
+               4: {-2 * plane, -plane, plane}}[kind]
+        offsets = sorted({0} | near | far)
+        values = rng.standard_normal(len(offsets))
+        m = sp.diags([np.full(n - abs(o), v) for o, v in zip(offsets, values)], offsets, shape=(n, n), format="csr")
+        m.sort_indices()
+        a = la.CrsMatrix(m.data.astype(np.float64), m.indices.astype(np.int64), m.indptr.astype(np.int64))
+        x = rng.standard_normal(n)
+        with la.Engine(a, 3, spmv="dict") as e:
+            seen.add(e.spmv_name[-1] if e.spmv_name[-1] in "ap" else "0")
+            y = e.spmv(x)
+            e.set_start(x)
+            alpha, _ = e.run(1)
+        want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
+        assert np.all(np.abs(y - want) <= spmv_tolerance(a, x)), (case, offsets, n)
+        xn = x / np.linalg.norm(x)
+        assert abs(alpha[0] - xn @ oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, xn)) < 1e-12 * np.abs(values).sum()
+        if len(offsets) <= 7:
+            with la.Engine(a, 3, spmv="rows") as e:
+                assert e.spmv(x).tobytes() == y.tobytes(), (case, offsets, n)
+    assert {"a", "p"} <= seen, seen
