@@ -114,6 +114,8 @@ struct Engine {
     int32_t *d_dlen = nullptr, *d_doff = nullptr;  // [patterns], [patterns][dict_stride]
     double *d_dval = nullptr;
     int dict_patterns = 0, dict_stride = 0, dict_halo = 0;
+    bool dict_values = true;   // false: the dictionary holds column offsets only (values read from the CRS array)
+    bool pdict = false;        // the row-wise CRS SpMV runs as a plane walk over such a dictionary
     int dict_blocks = 0;       // grid of the ahead-of-time form: one round of resident workgroups
     int dict_segs = 0, dict_seg_len = 0;   // plane-walking form: segments of planes per column of steps
     int32_t dict_plane_f = 0;  // plane-walking form: rows per plane (0: not a grid of whole-step planes)
@@ -150,7 +152,9 @@ struct Engine {
     int upload_crs(const int64_t *rp, const int64_t *ci, const double *va);
     int build_from_coo(const Coo *coo, int64_t length, int swap_row_column);
     int choose_spmv(int requested);
-    int build_dict();
+    int build_dict(bool with_values = true);
+    bool pdict_usable() const;
+    int launch_spmv_pdict(const double *x, const double *xdot, double *y, int *nparts);
     int dict_form() const;
     void free_dict();
     int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1);

@@ -390,6 +390,14 @@ int Engine::choose_spmv(int requested) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
     }
+    pdict = false;
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && !slab && nnz > 0) {
+        // stencil-like rows whose values do not repeat: their column offsets may (a grid with variable
+        // coefficients); the product then walks the grid's planes with the values read from the CRS array
+        if (int rc = build_dict(false)) return rc;
+        pdict = pdict_usable();
+        if (!pdict) free_dict();
+    }
     if (spmv_kind == LANCZOS_HIP_SPMV_MERGE)
         snprintf(spmv_name, sizeof(spmv_name), "merge%s", rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_DICT)
@@ -398,7 +406,7 @@ int Engine::choose_spmv(int requested) {
     else if (spmv_kind == LANCZOS_HIP_SPMV_PANEL)
         snprintf(spmv_name, sizeof(spmv_name), "panel%d%s", tile_bits, rp64 ? "_rp64" : "");
     else if (spmv_kind == LANCZOS_HIP_SPMV_ROWS)
-        snprintf(spmv_name, sizeof(spmv_name), "rows64%s", rp64 ? "_rp64" : "");
+        snprintf(spmv_name, sizeof(spmv_name), "rows64%s%s", rp64 ? "_rp64" : "", pdict ? "p" : "");  // p: plane walk
     else if (spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT)
         snprintf(spmv_name, sizeof(spmv_name), "pipe%d%s%s", 1 << log2r,
                  spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT ? "_nt" : "", rp64 ? "_rp64" : "");
@@ -498,6 +506,8 @@ int Engine::tile_blocks() const {
 double Engine::spmv_bytes() const {
     if (spmv_kind == LANCZOS_HIP_SPMV_DICT)  // what this format reads and writes: pattern numbers, x, y
         return 2.0 * (double)n + 8.0 * (double)n_ext + 8.0 * (double)n + 12.0 * (double)dict_patterns * dict_stride;
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && pdict)  // values and row offsets of the CRS arrays, pattern numbers, x, y
+        return 8.0 * (double)nnz + 4.0 * (double)(n + 1) + 2.0 * (double)n + 8.0 * (double)n_ext + 8.0 * (double)n;
     return 12.0 * (double)nnz + (rp64 ? 8.0 : 4.0) * (double)(n + 1) + 8.0 * (double)n_ext + 8.0 * (double)n;
 }
 
@@ -607,6 +617,7 @@ int Engine::launch_spmv(const double *x, const double *xdot, double *y, int *npa
     }
     if (spmv_kind == LANCZOS_HIP_SPMV_DICT) return launch_spmv_dict(x, xdot, y, nparts);
     if (spmv_kind == LANCZOS_HIP_SPMV_PANEL) return launch_spmv_panels(x, xdot, y, nparts);
+    if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && pdict) return launch_spmv_pdict(x, xdot, y, nparts);
     if (rp64)
         launch_spmv_t<int64_t>(this, x, xdot, y, nparts, 0, n, d_partials);
     else

@@ -127,3 +127,22 @@ def rmat_laplacian_gpu(scale, edge_factor=16, seed=1, abc=(0.57, 0.19, 0.19)):
     del col, val, row_head
     torch.cuda.empty_cache()
     return out
+
+
+class plain_rows:
+    """Environment for engines made inside the `with`: the row-wise CRS SpMV stays on the CRS arrays
+    (LANCZOS_HIP_ROWS_PLANES=0, read by every engine at creation) -- the form the other SpMV forms'
+    bits are compared with."""
+
+    def __enter__(self):
+        import os
+        self._old = os.environ.get("LANCZOS_HIP_ROWS_PLANES")
+        os.environ["LANCZOS_HIP_ROWS_PLANES"] = "0"
+
+    def __exit__(self, *exc):
+        import os
+        if self._old is None:
+            del os.environ["LANCZOS_HIP_ROWS_PLANES"]
+        else:
+            os.environ["LANCZOS_HIP_ROWS_PLANES"] = self._old
+        return False

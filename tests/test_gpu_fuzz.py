@@ -111,6 +111,10 @@ def test_random_stencils_through_the_dictionary_forms(gpu):
         xn = x / np.linalg.norm(x)
         assert abs(alpha[0] - xn @ oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, xn)) < 1e-12 * np.abs(values).sum()
         if len(offsets) <= 7:
-            with la.Engine(a, 3, spmv="rows") as e:
+            from matrices import plain_rows
+            with plain_rows(), la.Engine(a, 3, spmv="rows") as e:
+                assert e.spmv_name == "rows64" and e.spmv(x).tobytes() == y.tobytes(), (case, offsets, n)
+            with la.Engine(a, 3, spmv="rows") as e:      # as a plane walk over the offsets' dictionary where that applies
+                seen.add(e.spmv_name)
                 assert e.spmv(x).tobytes() == y.tobytes(), (case, offsets, n)
-    assert {"a", "p"} <= seen, seen
+    assert {"a", "p", "rows64", "rows64p"} <= seen, seen

@@ -13,7 +13,7 @@ import pytest
 
 import lanczos_amd as la
 import oracle
-from matrices import (laplacian3d_triplets_by_column, laplacian_eigs, laplacian_triplets_rowwise, rel_err,
+from matrices import (plain_rows, laplacian3d_triplets_by_column, laplacian_eigs, laplacian_triplets_rowwise, rel_err,
                       rmat_laplacian)
 
 pytestmark = pytest.mark.gpu
@@ -193,10 +193,17 @@ def test_dictionary_spmv_forms_on_grids(gpu):
             y = e.spmv(x)
             e.set_start(x)
             alpha, _ = e.run(2)
-        with la.Engine(a, 4, spmv="rows") as e:
-            assert e.spmv(x).tobytes() == y.tobytes(), N
+        with plain_rows(), la.Engine(a, 4, spmv="rows") as e:
+            assert e.spmv_name == "rows64" and e.spmv(x).tobytes() == y.tobytes(), N
             e.set_start(x)
             alpha_rows, _ = e.run(2)
+        # the same grid with the values out of the CRS array (the row-wise form on a dictionary of column offsets)
+        with la.Engine(a, 4, spmv="rows") as e:
+            assert e.spmv_name == ("rows64p" if N in (46, 47, 64, 96, 100) else "rows64"), (N, e.spmv_name)
+            assert e.spmv(x).tobytes() == y.tobytes(), N
+            e.set_start(x)
+            alpha_p, _ = e.run(2)
+        assert rel_err(alpha_p, alpha_rows) < 1e-13, N
         assert rel_err(alpha, alpha_rows) < 1e-13, N
         want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
         assert np.all(np.abs(y - want) <= spmv_tolerance(a, x)), N
@@ -225,8 +232,32 @@ def test_dictionary_spmv_forms_on_grids(gpu):
         with la.Engine(b, 3, spmv="dict") as e:
             assert e.spmv_name.endswith("p")
             y = e.spmv(x)
-        with la.Engine(b, 3, spmv="rows") as e:
+        with plain_rows(), la.Engine(b, 3, spmv="rows") as e:
             assert e.spmv(x).tobytes() == y.tobytes(), n
+        with la.Engine(b, 3, spmv="rows") as e:
+            assert e.spmv_name == "rows64p" and e.spmv(x).tobytes() == y.tobytes(), n
+
+
+def test_stencil_with_variable_coefficients_walks_the_planes(gpu):
+    """Rows whose column offsets repeat while their values do not (a 7-point stencil with random coefficients):
+    no dictionary of (offset, value) patterns exists, the automatic choice is the row-wise form, and that one
+    runs as a plane walk over a dictionary of offsets with the values read from the CRS array.  Bits of the
+    plain row-wise kernel (src/crs.c:172-175 order), Lanczos sequences of the oracle."""
+    for N in (64, 47):
+        a = la.synth_laplacian(3, N)
+        rng = np.random.default_rng(N)
+        b = la.CrsMatrix(a.values * (1.0 + 0.5 * rng.random(a.length)), a.column_index, a.row_head_indexes)
+        x = rng.standard_normal(b.dimension)
+        with la.Engine(b, 12) as e:
+            assert e.spmv_name == "rows64p", e.spmv_name
+            y = e.spmv(x)
+            v0 = la.gaussian_fill(5, 0, b.dimension)
+            e.set_start(v0)
+            alpha, beta = e.run(10)
+        with plain_rows(), la.Engine(b, 3) as e:
+            assert e.spmv_name == "rows64" and e.spmv(x).tobytes() == y.tobytes(), N
+        o = oracle.lanczos_crs(b.row_head_indexes, b.column_index, b.values, v0, 4, 11, 0.0)
+        assert rel_err(alpha, o.alpha) < 1e-12 and rel_err(beta, o.beta) < 1e-12
 
 
 def test_dictionary_spmv_on_repeating_rows(gpu):
@@ -240,7 +271,7 @@ def test_dictionary_spmv_on_repeating_rows(gpu):
             v0 = la.gaussian_fill(3, 0, a.dimension)
             e.set_start(v0)
             alpha, beta = e.run(30)
-        with la.Engine(a, 3, spmv="rows") as e:
+        with plain_rows(), la.Engine(a, 3, spmv="rows") as e:
             assert e.spmv(x).tobytes() == y.tobytes()
         want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
         assert np.all(np.abs(y - want) <= spmv_tolerance(a, x))
