@@ -338,8 +338,15 @@ def single_gpu(args, keeper=None) -> dict:
     # iteration whose bytes do not grow with k
     eng.close()
 
-    def vector_step(spmv_choice):
-        e2 = la.Engine(a, 4, reorth="none", spmv=spmv_choice, profile=True)
+    def vector_step(spmv_choice, plain_rows=False):
+        # plain_rows: the row-wise form on the CRS arrays as they are (by default it walks a grid's planes over a
+        # dictionary of column offsets, with the values read from the CRS array); read by the engine at creation
+        if plain_rows:
+            os.environ["LANCZOS_HIP_ROWS_PLANES"] = "0"
+        try:
+            e2 = la.Engine(a, 4, reorth="none", spmv=spmv_choice, profile=True)
+        finally:
+            os.environ.pop("LANCZOS_HIP_ROWS_PLANES", None)
         e2.set_start(v0)
         e2.run(5)
         e2.profile_reset()
@@ -361,7 +368,9 @@ def single_gpu(args, keeper=None) -> dict:
             "iters_per_s": S / dt2,
             "ms_per_iter": dt2 / S * 1e3,
             "spmv_kernel": name,
-            "matrix_format": "row-pattern dictionary" if name.startswith("dict") else "CRS",
+            "matrix_format": "row-pattern dictionary" if name.startswith("dict") else
+                             "CRS values and row offsets + column-offset patterns" if name.startswith("rows") and name.endswith("p")
+                             else "CRS",
             "format_bytes_per_iter": fmt_iter,
             "achieved_GBps": fmt_iter * S / dt2 / 1e9,
             "frac_of_hbm_peak": fmt_iter * S / dt2 / 1e9 / HBM_PEAK_GBPS,
@@ -379,12 +388,18 @@ def single_gpu(args, keeper=None) -> dict:
             "frac_of_hbm_peak_moved": (fmt_spmv + 32.0 * n) * S / dt2 / 1e9 / HBM_PEAK_GBPS,
         }
 
+    sv_crs_planes = None
     if args.main_only:
         sv = sv_crs = {"spmv_kernel": spmv_name_main, "spmv_GBps": None}
     else:
         sv = vector_step(args.spmv)
-        # the same step on the plain CRS arrays (what the shared algorithmic-byte figure describes)
-        sv_crs = vector_step("rows") if sv["spmv_kernel"].startswith("dict") else sv
+        # the same step on the plain CRS arrays (what the shared algorithmic-byte figure describes), and with the
+        # column array replaced by pattern numbers (what a grid with variable coefficients runs on)
+        if sv["spmv_kernel"].startswith("dict"):
+            sv_crs = vector_step("rows", plain_rows=True)
+            sv_crs_planes = vector_step("rows")
+        else:
+            sv_crs = sv
     spmv_name = sv["spmv_kernel"]
 
     out = {
@@ -411,6 +426,7 @@ def single_gpu(args, keeper=None) -> dict:
         "spmv_hbm_GBps": sv_crs["spmv_GBps"],
         "spmv_vector_step": sv,
         "spmv_vector_step_crs": sv_crs,
+        "spmv_vector_step_crs_values": sv_crs_planes,
         "kernel_ms_total": {k: v["ms"] for k, v in prof.items()},
         "kernel_launches": {k: v["launches"] for k, v in prof.items()},
         "kernel_algorithmic_bytes_total": {k: v["bytes"] for k, v in prof.items()},

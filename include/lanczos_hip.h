@@ -107,6 +107,10 @@ typedef struct crs {
  *                          default the row blocks' weights decide)
  *   LANCZOS_HIP_TILE_ROWBITS 11 to 14: rows per block of the tiled SpMV as a power of two (default: even
  *                          schedule 12, 11 for vectors up to 128 MiB; uneven 13, 14 beyond 256 MiB)
+ *   LANCZOS_HIP_ROWS_PLANES 0: the row-wise CRS SpMV stays on the CRS arrays as they are; by default, when the rows'
+ *                          column offsets repeat as patterns and the matrix is a grid in three dimensions (rows of
+ *                          up to eight entries, fewer than 2^29 entries), it walks the grid's planes over a dictionary
+ *                          of column offsets and reads the values from the CRS array (same bits)
  *   LANCZOS_HIP_ROWS_MASK  0: the row-wise CRS SpMV loads whole tiles instead of ending each group's loads at
  *                          its last entry (for comparison)
  *   LANCZOS_HIP_DICT_PLANES / LANCZOS_HIP_DICT_AHEAD / LANCZOS_HIP_DICT_WIDE  0 switches off, in turn, the
