@@ -425,156 +425,14 @@ static size_t dict_planes_lds_bytes(int halo, int patterns, int stride) {
            sizeof(uint16_t) * kDictSpan + 16;
 }
 
-template <int WPT>
-__global__ void __launch_bounds__(kPlanesBlock)
-k_spmv_dict_planes(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
-                   const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
-                   int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
-                   const double *__restrict__ x,
-                   const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
-                   int64_t dot_lo, int64_t dot_hi) {
-    constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
-    static_assert(ROWS == 2, "two rows per thread");
-    extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
-    __shared__ double red[BLOCK / 64];
-    const int tid = threadIdx.x;
-    const int wlen = kDictSpan + 2 * halo;
-    const int tab = patterns * stride;
-    double *s_zero = win + 3 * wlen;
-    double *s_val = s_zero + kDictSpan;
-    int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + tab);
-    uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + 3 * tab + ((3 * tab) & 1));
-    for (int i = tid; i < tab; i += BLOCK) {
-        const int off = doff[i];
-        const bool absent = i % stride >= dlen[i / stride];
-        s_val[i] = absent ? -0.0 : dval[i];   // (-0.0) x (+0.0) added to a sum leaves it as it is, signed zeros included
-#pragma unroll
-        for (int rot = 0; rot < 3; ++rot) {
-            // ring slot `rot` holds this step's window, the slot before it the previous plane's, the slot after it the next one's
-            int e;
-            if (absent) e = 3 * wlen;
-            else if (off >= -halo && off <= halo) e = rot * wlen + halo + off;
-            else if (off == far_a) e = ((rot + 2) % 3) * wlen + halo;                       // a slab's remote plane before
-            else if (off == far_b) e = ((rot + 1) % 3) * wlen + halo;                       // ... and after
-            else if (off < 0) e = ((rot + 2) % 3) * wlen + halo + (off + plane_rows);       // around -F: the window F back
-            else e = ((rot + 1) % 3) * wlen + halo + (off - plane_rows);                    // around +F: the window F ahead
-            s_idx[rot * tab + i] = e;
-        }
-    }
-    for (int i = tid; i < kDictSpan; i += BLOCK) s_zero[i] = 0.0;
-    // work item = (column of steps, segment of planes); XCD b % 8 takes a contiguous eighth of the items
-    const int64_t items = (int64_t)cols * segs;
-    const int64_t per_xcd = (items + 7) >> 3;
-    const int64_t item = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    const bool live = (int64_t)(blockIdx.x >> 3) < per_xcd && item < items;
-    const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)(uint32_t)((uint64_t)n_ext << 3), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rpat = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)pattern, 0, (int)(uint32_t)((((uint64_t)n << 1) + 3) & ~(uint64_t)3), 0x00020000);
-    double acc = 0.0;
-    if (live) {
-        const int col = (int)(item % cols), seg = (int)(item / cols);
-        const int zb = seg * seg_len, ze = min(zb + seg_len, planes);
-        dict_d2 W[WPT / 2];
-        uint32_t pq;
-        // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
-        // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
-        const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
-        auto row_of = [&](int z) -> int64_t {
-            int64_t row = (int64_t)z * plane_rows + (int64_t)col * kDictSpan;
-            if (z < 0 && far_a != INT32_MIN) row = far_a + (int64_t)col * kDictSpan;
-            if (z >= planes && far_b != INT32_MIN) row = far_b + (int64_t)(planes - 1) * plane_rows + (int64_t)col * kDictSpan;
-            return row;
-        };
-        // a plane outside the grid, or rows past the end, read as zeros (or as rows no entry refers to)
-        auto load_window = [&](int z) {
-            const int64_t row0 = row_of(z);
-#pragma unroll
-            for (int k = 0; k < WPT / 2; ++k)
-                W[k] = __builtin_bit_cast(dict_d2, __builtin_amdgcn_raw_buffer_load_b128(
-                                                       rx, (int)((uint32_t)(row0 - halo + 2 * (k * BLOCK + tid)) << 3), 0, 0));
-        };
-        auto store_window = [&](int slot) {
-#pragma unroll
-            for (int k = 0; k < WPT / 2; ++k)
-                if (2 * (k * BLOCK + tid) < wlen)
-                    *reinterpret_cast<dict_d2 *>(win + slot * wlen + 2 * (k * BLOCK + tid)) = W[k];
-        };
-        auto load_patterns = [&](int z) {
-            pq = __builtin_amdgcn_raw_buffer_load_b32(rpat, (int)((uint32_t)(row_of(z) + 2 * tid) << 1), 0, 0);
-        };
-        auto step = [&](int z, auto rot_tag) {
-            constexpr int ROT = decltype(rot_tag)::value;
-            const int64_t row0 = row_of(z);
-            __syncthreads();  // the previous step's readers are done
-            store_window((ROT + 1) % 3);
-            *reinterpret_cast<uint32_t *>(s_pat + 2 * tid) = pq;
-            if (z + 1 < ze) {
-                load_window(z + 2);
-                load_patterns(z + 1);
-            }
-            __syncthreads();
-            const int32_t *idx = s_idx + ROT * tab;
-            int base[ROWS];
-            double sum[ROWS];
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
-                base[u] = (int)s_pat[u * BLOCK + tid] * stride;
-                sum[u] = 0.0;
-            }
-            for (int j = 0; j < stride; ++j) {
-#pragma unroll
-                for (int u = 0; u < ROWS; ++u) sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + idx[base[u] + j]];
-            }
-#pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
-                const int64_t r = row0 + u * BLOCK + tid;
-                if (r < n && u * BLOCK + tid < lim) {
-                    double xd = win[ROT * wlen + halo + u * BLOCK + tid];
-                    if (xdot != x) xd = xdot[r];
-                    const double t = xd * sum[u];
-                    acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
-                }
-            }
-            // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first row set, the odd
-            // lane those of the second
-            const bool odd = tid & 1;
-            const double mine = odd ? sum[1] : sum[0];
-            const double got = __shfl_xor(odd ? sum[0] : sum[1], 1);
-            const dict_d2 s2 = odd ? dict_d2{got, mine} : dict_d2{mine, got};
-            const int l2 = (odd ? BLOCK : 0) + (tid & ~1);
-            const int64_t r2 = row0 + l2;
-            if (r2 + 1 < n && l2 + 1 < lim) __builtin_nontemporal_store(s2, reinterpret_cast<dict_d2 *>(y + r2));
-            else if (r2 < n && l2 < lim) __builtin_nontemporal_store(s2.x, y + r2);
-        };
-        // the planes before and of the first step go to ring slots 0 and 1, the one after it waits in registers
-        load_window(zb - 1);
-        store_window(0);
-        load_window(zb);
-        store_window(1);
-        load_window(zb + 1);
-        load_patterns(zb);
-        for (int z = zb; z < ze; z += 3) {
-            step(z, std::integral_constant<int, 1>{});
-            if (z + 1 < ze) step(z + 1, std::integral_constant<int, 2>{});
-            if (z + 2 < ze) step(z + 2, std::integral_constant<int, 0>{});
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-}
-
-// The row-wise CRS product as a plane walk: when the rows' column OFFSETS repeat as patterns although their
-// values do not (a stencil with variable coefficients), the column array is replaced by one pattern number
-// per row and x is taken from the ring of windows as above; the values are read from the CRS array where
+// CRS_VALUES: the row-wise CRS product as a plane walk.  When the rows' column OFFSETS repeat as patterns although
+// their values do not (a stencil with variable coefficients), the column array is replaced by one pattern number
+// per row and x is taken from the ring of windows just the same; the values are read from the CRS array where
 // they lie, through the row offsets (src/crs.c:155-178 reads values, column indices and row offsets: 16 bytes
 // per entry; this form 8 bytes per entry plus 6 per row).  Rows of up to eight entries; sums left to right.
-template <int WPT, typename RP>
+template <int WPT, bool CRS_VALUES>
 __global__ void __launch_bounds__(kPlanesBlock)
-k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict__ rp, const double *__restrict__ val, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
+k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restrict__ rp, const double *__restrict__ val, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                    int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
                    const double *__restrict__ x,
@@ -591,8 +449,9 @@ k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict_
     double *s_val = s_zero + kDictSpan;
     int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + tab);
     uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + 3 * tab + ((3 * tab) & 1));
-    int32_t *s_len = reinterpret_cast<int32_t *>(s_pat + kDictSpan);
-    for (int i = tid; i < patterns; i += BLOCK) s_len[i] = dlen[i];
+    int32_t *s_len = reinterpret_cast<int32_t *>(s_pat + kDictSpan);   // CRS_VALUES only
+    if (CRS_VALUES)
+        for (int i = tid; i < patterns; i += BLOCK) s_len[i] = dlen[i];
     for (int i = tid; i < tab; i += BLOCK) {
         const int off = doff[i];
         const bool absent = i % stride >= dlen[i / stride];
@@ -630,7 +489,7 @@ k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict_
         const int zb = seg * seg_len, ze = min(zb + seg_len, planes);
         dict_d2 W[WPT / 2];
         uint32_t pq;
-        RP head[ROWS];   // where this thread's rows of the next step begin in the value array
+        int32_t head[ROWS];   // where this thread's rows of the next step begin in the value array
         // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
         // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
         const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
@@ -657,10 +516,12 @@ k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict_
         auto load_patterns = [&](int z) {
             const int64_t row0 = row_of(z);
             pq = __builtin_amdgcn_raw_buffer_load_b32(rpat, (int)((uint32_t)(row0 + 2 * tid) << 1), 0, 0);
+            if constexpr (CRS_VALUES) {
 #pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
-                const int64_t r = row0 + u * BLOCK + tid;
-                head[u] = rp[r < n ? r : n];
+                for (int u = 0; u < ROWS; ++u) {
+                    const int64_t r = row0 + u * BLOCK + tid;
+                    head[u] = rp[r < n ? r : n];
+                }
             }
         };
         auto step = [&](int z, auto rot_tag) {
@@ -669,14 +530,16 @@ k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict_
             __syncthreads();  // the previous step's readers are done
             store_window((ROT + 1) % 3);
             *reinterpret_cast<uint32_t *>(s_pat + 2 * tid) = pq;
-            // this step's values: a row's entries lie side by side in the CRS array, two per load
+            // CRS_VALUES: this step's values; a row's entries lie side by side in the CRS array, two per load
             dict_d2 V[ROWS][4];
+            if constexpr (CRS_VALUES) {
 #pragma unroll
-            for (int u = 0; u < ROWS; ++u)
+                for (int u = 0; u < ROWS; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    V[u][q] = __builtin_bit_cast(dict_d2, __builtin_amdgcn_raw_buffer_load_b128(
-                                                              rval, (int)(((uint32_t)head[u] + 2 * q) << 3), 0, 0));
+                    for (int q = 0; q < 4; ++q)
+                        V[u][q] = __builtin_bit_cast(dict_d2, __builtin_amdgcn_raw_buffer_load_b128(
+                                                                  rval, (int)(((uint32_t)head[u] + 2 * q) << 3), 0, 0));
+            }
             if (z + 1 < ze) {
                 load_window(z + 2);
                 load_patterns(z + 1);
@@ -689,18 +552,25 @@ k_spmv_pdict_planes(int64_t n, int64_t n_ext, int64_t nnz, const RP *__restrict_
             for (int u = 0; u < ROWS; ++u) {
                 const int pid = (int)s_pat[u * BLOCK + tid];
                 base[u] = pid * stride;
-                len[u] = s_len[pid];
+                len[u] = CRS_VALUES ? s_len[pid] : 0;
                 sum[u] = 0.0;
             }
-            // up to eight entries per row (checked by the launcher), left to right; an entry the row does not have
-            // multiplies -0.0 by the zeros' region
+            if constexpr (CRS_VALUES) {
+                // up to eight entries per row (checked by the launcher), left to right; an entry the row does not
+                // have multiplies -0.0 by the zeros' region
 #pragma unroll
-            for (int u = 0; u < ROWS; ++u) {
+                for (int u = 0; u < ROWS; ++u) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const double v = j < len[u] ? (j & 1 ? V[u][j >> 1].y : V[u][j >> 1].x) : -0.0;
-                    const int e = j < stride ? idx[base[u] + j] : 3 * wlen;
-                    sum[u] += v * win[u * BLOCK + tid + e];
+                    for (int j = 0; j < 8; ++j) {
+                        const double v = j < len[u] ? (j & 1 ? V[u][j >> 1].y : V[u][j >> 1].x) : -0.0;
+                        const int e = j < stride ? idx[base[u] + j] : 3 * wlen;
+                        sum[u] += v * win[u * BLOCK + tid + e];
+                    }
+                }
+            } else {
+                for (int j = 0; j < stride; ++j) {
+#pragma unroll
+                    for (int u = 0; u < ROWS; ++u) sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + idx[base[u] + j]];
                 }
             }
 #pragma unroll
@@ -1003,9 +873,9 @@ int Engine::dict_form() const {
 using DictAheadKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, int, const int32_t *, const int32_t *,
                                  const double *, int, int, const double *, const double *, double *, double *, int64_t,
                                  int64_t);
-using DictPlanesKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, int, const int32_t *, const int32_t *,
-                                  const double *, int, int, int, int, int, int, int, const double *, const double *,
-                                  double *, double *, int64_t, int64_t);
+using DictPlanesKernel = void (*)(int64_t, int64_t, int64_t, const int32_t *, const double *, const uint16_t *, int, int,
+                                  int, const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
+                                  const double *, const double *, double *, double *, int64_t, int64_t);
 
 // window doubles per thread (even: loaded in pairs) for a window of `wlen` doubles and `block` threads
 static int dict_window_per_thread(int wlen, int block) { return 2 * ((wlen / 2 + block - 1) / block); }
@@ -1028,10 +898,6 @@ static int dict_resident(K kernel, int block, size_t lds) {
     return occ;
 }
 
-using PdictKernel32 = void (*)(int64_t, int64_t, int64_t, const int32_t *, const double *, const uint16_t *, int, int, int,
-                                const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
-                                const double *, const double *, double *, double *, int64_t, int64_t);
-
 static size_t pdict_lds_bytes(int halo, int patterns, int stride) {
     return dict_planes_lds_bytes(halo, patterns, stride) + sizeof(int32_t) * (size_t)patterns + 8;
 }
@@ -1052,9 +918,9 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
     const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
     const size_t lds = pdict_lds_bytes(dict_halo, dict_patterns, dict_stride);
     const int w = dict_window_per_thread(wlen, kPlanesBlock);
-    const PdictKernel32 kernel = w <= 4   ? k_spmv_pdict_planes<4, int32_t>
-                                 : w <= 6 ? k_spmv_pdict_planes<6, int32_t>
-                                          : k_spmv_pdict_planes<10, int32_t>;
+    const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, true>
+                                 : w <= 6 ? k_spmv_dict_planes<6, true>
+                                          : k_spmv_dict_planes<10, true>;
     if (dict_blocks == 0) {
         const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
         dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -1088,7 +954,9 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
         const int w = dict_window_per_thread(wlen, kPlanesBlock);
-        const DictPlanesKernel kernel = w <= 4 ? k_spmv_dict_planes<4> : w <= 6 ? k_spmv_dict_planes<6> : k_spmv_dict_planes<10>;
+        const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, false>
+                                        : w <= 6 ? k_spmv_dict_planes<6, false>
+                                                 : k_spmv_dict_planes<10, false>;
         if (dict_blocks == 0) {
             const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
             dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -1097,8 +965,9 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
             dict_blocks = (int)(((int64_t)cols * dict_segs + 7) / 8 * 8);
         }
         *nparts = dict_blocks;
-        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, pat, dict_patterns,
-                           dict_stride, dict_halo, dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
+        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, nnz,
+                           (const int32_t *)nullptr, (const double *)nullptr, pat, dict_patterns, dict_stride, dict_halo,
+                           dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
                            cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);
     } else if (form == 1) {
         // loads one step ahead; 16-byte loads when no pair of doubles can straddle the start of x
