@@ -10,6 +10,11 @@
 // row-wise kernel computes.  The dictionary is found on the device (hash per
 // row, sort, unique) and every row is then compared entry by entry with its
 // pattern: a hash collision cannot slip through.
+//
+// Three forms of the product, chosen per dictionary (Engine::dict_form): k_spmv_dict (loads inside the
+// workgroup step; any dictionary), k_spmv_dict_ahead (loads one step ahead, at most two distinct far
+// offsets), k_spmv_dict_planes (grids in three dimensions, walked plane by plane; also the row-wise CRS
+// product of a grid whose values do not repeat, over a dictionary of column offsets alone).
 #include <hipcub/hipcub.hpp>
 
 #include <limits.h>
@@ -410,8 +415,8 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
     }
 }
 
-// Grids in three dimensions: the two far offsets are -F and +F (one plane of the grid back and ahead).
-// A workgroup that walks from plane to plane -- rows [c, c + kDictSpan) of plane z, then the same rows
+// Grids in three dimensions: the far offsets lie at -F and +F (one plane of the grid back and ahead) or within
+// the window's halo of them.  A workgroup that walks from plane to plane -- rows [c, c + kDictSpan) of plane z, then the same rows
 // of plane z + 1, F rows further -- finds its far entries in the windows of the step before and the
 // step after.  Three windows stay in LDS (a ring), every step loads
 // one, and x is fetched 1.5 times per product (the windows' halos) in place of 3.5 times; the form above
