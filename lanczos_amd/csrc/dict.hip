@@ -812,7 +812,12 @@ int Engine::build_dict(bool with_values) {
                 hi = negatives ? std::max<int64_t>(hi, o) : o;
                 ++negatives;
             }
-        const int64_t F = negatives ? ((-(lo + hi) / 2) + 1) & ~(int64_t)1 : 0;
+        int64_t F = negatives ? ((-(lo + hi) / 2) + 1) & ~(int64_t)1 : 0;
+        // No far offsets at all (grids in one or two dimensions, small ones in three): the row-wise CRS
+        // product over a dictionary of offsets walks "planes" of 64 steps, or of a third of the rows, whose
+        // neighbouring windows no entry refers to.  (The dictionary with values keeps its form without far loads.)
+        if (far.empty() && !dict_values)
+            F = std::min<int64_t>(64 * kDictSpan, n / 3 / kDictSpan * kDictSpan);
         if (ok && F > 0 && F * 3 <= n && F < INT32_MAX) {
             std::vector<int32_t> others;
             bool exact = negatives == 1 && -lo == F;

@@ -132,7 +132,7 @@ def test_spmv_zero_matrix_and_auto_kernel(gpu, monkeypatch):
         assert e.spmv_name == "dict27a"          # a cube's rows: interior, 6 faces, 12 edges, 8 corners; N^2 <= 2048: no far entries
     monkeypatch.setenv("LANCZOS_HIP_NO_DICT", "1")
     with la.Engine(la.synth_laplacian(3, 16), 3) as e:
-        assert e.spmv_name == "rows64"           # stencil: neighbouring rows hold neighbouring columns
+        assert e.spmv_name == "rows64p"          # stencil: neighbouring rows hold neighbouring columns (offsets as patterns)
     monkeypatch.delenv("LANCZOS_HIP_NO_DICT")
     with la.Engine(la.synth_laplacian(3, 16), 3, spmv="pipe") as e:
         assert e.spmv_name == "pipe64"
@@ -199,6 +199,7 @@ def test_dictionary_spmv_forms_on_grids(gpu):
             alpha_rows, _ = e.run(2)
         # the same grid with the values out of the CRS array (the row-wise form on a dictionary of column offsets)
         with la.Engine(a, 4, spmv="rows") as e:
+            # (12^3: too few rows; 32 to 45: three windows with halos of N^2 entries are beyond 64 KiB of LDS)
             assert e.spmv_name == ("rows64p" if N in (46, 47, 64, 96, 100) else "rows64"), (N, e.spmv_name)
             assert e.spmv(x).tobytes() == y.tobytes(), N
             e.set_start(x)
@@ -241,10 +242,11 @@ def test_dictionary_spmv_forms_on_grids(gpu):
 def test_stencil_with_variable_coefficients_walks_the_planes(gpu):
     """Rows whose column offsets repeat while their values do not (a 7-point stencil with random coefficients):
     no dictionary of (offset, value) patterns exists, the automatic choice is the row-wise form, and that one
-    runs as a plane walk over a dictionary of offsets with the values read from the CRS array.  Bits of the
-    plain row-wise kernel (src/crs.c:172-175 order), Lanczos sequences of the oracle."""
-    for N in (64, 47):
-        a = la.synth_laplacian(3, N)
+    runs as a plane walk over a dictionary of offsets with the values read from the CRS array -- on grids in
+    one and two dimensions too, whose "planes" no entry reaches across.  Bits of the plain row-wise kernel
+    (src/crs.c:172-175 order), Lanczos sequences of the oracle."""
+    for d, N in ((3, 64), (3, 47), (2, 300), (1, 70001)):   # (more rows than a dictionary with values may hold patterns)
+        a = la.synth_laplacian(d, N)
         rng = np.random.default_rng(N)
         b = la.CrsMatrix(a.values * (1.0 + 0.5 * rng.random(a.length)), a.column_index, a.row_head_indexes)
         x = rng.standard_normal(b.dimension)
