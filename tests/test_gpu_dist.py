@@ -33,8 +33,8 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     import lanczos_amd as la
     from lanczos_amd import dist as ld
     torch.cuda.set_device(0)
-    if kind == "lap3d":
-        N = 40
+    if kind.startswith("lap3d"):
+        N = 48 if kind == "lap3d48" else 40   # 48: planes of 2304 rows lie beyond the window: the slabs walk them
         n = N ** 3
         bounds = ld.partition_rows(n, world)
         a_local = la.synth_laplacian_rows(3, N, bounds[rank], bounds[rank + 1])
@@ -73,6 +73,8 @@ def _worker(rank, world, port, kind, mode, reorth, steps, q):
     ("lap3d", "auto", "selective", "halo"),
     ("lap3d", "auto", "cuda_compat", "halo"),
     ("random_big", "auto", "none", "allgather"),
+    ("lap3d48", "auto", "full", "halo"),
+    ("lap3d48", "auto", "none", "halo"),
 ])
 def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
     ctx = mp.get_context("spawn")
@@ -87,8 +89,10 @@ def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
         assert p.exitcode == 0
     assert chosen == expect
     assert ea < 1e-11 and eb < 1e-11, (ea, eb)
-    if kind == "lap3d" and expect == "halo":
+    if kind.startswith("lap3d") and expect == "halo":
         assert kernel.startswith("dict") and overlapped      # split product, remote entries in the vectors' tails
+    if kind == "lap3d48":
+        assert kernel.endswith("p")    # plane walk, the neighbour's plane (in the vector's tail) before the first / after the last
     if kind == "random_big":
         assert kernel.startswith("panel")
 
