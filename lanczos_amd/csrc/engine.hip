@@ -319,6 +319,9 @@ int Engine::choose_spmv(int requested) {
     if (spmv_kind == LANCZOS_HIP_SPMV_AUTO && !no_dict && stats[1] > 0 && 2 * stats[2] > stats[1]) {
         // neighbouring rows hold neighbouring columns: rows are likely to repeat as patterns
         if (int rc = build_dict()) return rc;
+        // a dictionary in which a pattern serves fewer than four rows on average (values that do not repeat, up to
+        // 65535 rows) is the matrix over again: left to the row-wise forms
+        if (dict_patterns > 0 && (int64_t)dict_patterns * 4 > n) free_dict();
         if (dict_patterns > 0) spmv_kind = LANCZOS_HIP_SPMV_DICT;
     }
     if (spmv_kind == LANCZOS_HIP_SPMV_DICT && dict_patterns == 0) {
