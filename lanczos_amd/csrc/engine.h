@@ -16,6 +16,15 @@ constexpr int kMaxDotsSegment = 1024;  // basis vectors per k_dots launch (32 Ki
 int fail(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
 const char *last_error();
 
+struct Engine;
+// Which row slab of a several-GPU handle the calling thread has made current (-1: none).  HIP wants
+// the device of a stream current when an event is created for it or recorded on it; with every slab
+// on ONE device (the loopback transport) HIP cannot tell a call made under the wrong slab from a
+// right one, this number can.  LANCZOS_HIP_CHECK_AFFINITY=1 turns the comparison on: an engine of a
+// several-GPU handle then refuses calls made while another slab is current.
+extern thread_local int tl_current_slab;
+int check_affinity(const Engine *e, const char *where);
+
 // The body of an extern "C" entry point: no C++ exception (a failed host allocation above all) may
 // cross the C boundary; it becomes the usual message + EXIT_FAILURE.
 template <class F>
@@ -46,6 +55,7 @@ struct Engine {
     int nvec = 0;          // resident basis vectors (max_iter, or a ring of 3)
     int reorth = 0;
     int device = -1;
+    int affinity_id = -1;  // slab number inside a several-GPU handle (-1: an engine of its own)
     int cus = 0;
     int max_blocks = 0;    // 8 workgroups per CU, multiple of 8
     // what the matrix upload took (host arrays page-locked around the copies unless LANCZOS_HIP_PIN_UPLOAD=0)
@@ -206,6 +216,8 @@ struct Engine {
     int spmv_host(const double *x_host, double *y_host);
     int spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev);
     int enable_host_history();
+    int make_current();                 // this engine's device becomes the thread's current one
+    int record_event(hipEvent_t ev);    // on this engine's stream; its device must be current
 
     hipEvent_t take_event();
     void harvest_profile();

@@ -32,6 +32,16 @@ int fail(const char *fmt, ...) {
 
 const char *last_error() { return g_err; }
 
+thread_local int tl_current_slab = -1;
+
+int check_affinity(const Engine *e, const char *where) {
+    if (e->affinity_id < 0 || tl_current_slab == e->affinity_id) return 0;
+    const char *s = getenv("LANCZOS_HIP_CHECK_AFFINITY");  // read per call: only slabs under the wrong device get here
+    if (!s || atoi(s) == 0) return 0;
+    return fail("%s: slab %d's stream used while slab %d is current (its device would not be the current one on a "
+                "node with one GPU per slab)", where, e->affinity_id, tl_current_slab);
+}
+
 #define HIP_TRY(call)                                                                         \
     do {                                                                                      \
         hipError_t st__ = (call);                                                             \
@@ -674,6 +684,7 @@ int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
 // ---------------------------------------------------------------------------
 int Engine::set_start(const double *v0, bool normalise, double scale) {
     if (!v0) return fail("lanczos_hip_set_start: NULL vector");
+    if (int rc = check_affinity(this, "set_start")) return rc;
     HIP_TRY(hipSetDevice(device));
     // clear every slot: a second run must not see the previous basis
     HIP_TRY(hipMemsetAsync(d_V, 0, sizeof(double) * (size_t)ldv * (size_t)nvec, stream));
@@ -706,6 +717,7 @@ int Engine::set_start(const double *v0, bool normalise, double scale) {
 // iteration phases
 // ---------------------------------------------------------------------------
 int Engine::check_can_step() {
+    if (int rc = check_affinity(this, "iteration")) return rc;
     if (!started) return fail("lanczos_hip: no start vector set");
     if (reorth != LANCZOS_HIP_REORTH_NONE && k >= max_iter - 1)
         return fail("lanczos_hip: basis full (%d iterations of max_iter=%d done)", k, max_iter);
@@ -816,6 +828,7 @@ bool Engine::can_split_product() const {
 
 // The remote entries have arrived: the rows that read them, then the reductions as phase_spmv.
 int Engine::phase_spmv_end(double *red) {
+    if (int rc = check_affinity(this, "phase_spmv_end")) return rc;
     if (pending_lo < 0) return fail("lanczos_hip_phase_spmv_end: no product pending");
     int np = 0;
     if (int rc = launch_spmv_edges(pending_lo, pending_hi, d_partials + alpha_count, &np)) return rc;
@@ -827,6 +840,7 @@ int Engine::phase_spmv_end(double *red) {
 // Recurrence with deferred normalisation on a row slab: red[0] = u_k . A u_k and red[1] = |u_k|^2,
 // both summed over ranks.  Leaves the slab's partials of |u_{k+1}|^2 for the next phase_spmv.
 int Engine::phase_recur_lazy(double *red) {
+    if (int rc = check_affinity(this, "phase_recur_lazy")) return rc;
     if (!lazy_slab) return fail("lanczos_hip_phase_recur_lazy: needs reorth=none on a row-partitioned engine");
     const int blocks = vec_blocks();
     {
@@ -844,12 +858,14 @@ int Engine::phase_recur_lazy(double *red) {
 
 // beta of the last deferred iteration: red[0] = this slab's |u_k|^2 ...
 int Engine::phase_lazy_norm(double *red) {
+    if (int rc = check_affinity(this, "phase_lazy_norm")) return rc;
     if (!lazy_slab || k == 0) return fail("lanczos_hip_phase_lazy_norm: nothing deferred");
     return launch_finalize(norm_parts(k - 1), norm_count, red);
 }
 
 // ... and, summed over ranks, beta_{k-1} = sqrt(red[0]) into the history
 int Engine::phase_lazy_close(double *red) {
+    if (int rc = check_affinity(this, "phase_lazy_close")) return rc;
     if (!lazy_slab || k == 0) return fail("lanczos_hip_phase_lazy_close: nothing deferred");
     double *bhost = h_hist ? h_hist + 2 * (size_t)(k - 1) + 1 : nullptr;
     hipLaunchKernelGGL(k_lazy_flush, dim3(1), dim3(kBlock), 0, stream, (const double *)red, 1, d_beta + (k - 1), bhost);
@@ -885,6 +901,7 @@ int Engine::launch_scale(const double *parts, int cnt) {
 }
 
 int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
+    if (int rc = check_affinity(this, "phase_recur")) return rc;
     if (lazy_slab) return fail("lanczos_hip_phase_recur: reorth=none on a row slab runs phase_recur_lazy");
     if (reorth == LANCZOS_HIP_REORTH_MGS)
         return fail("lanczos_hip_phase_recur: the one-vector-at-a-time order (mgs) is not available phase by phase "
@@ -909,6 +926,7 @@ int Engine::phase_recur(double *red, int *n_red, int *is_norm) {
 }
 
 int Engine::phase_dots(double *red, int *n_red) {
+    if (int rc = check_affinity(this, "phase_dots")) return rc;
     int l0, l1;
     reorth_range(&l0, &l1);
     *n_red = l1 - l0;
@@ -918,6 +936,7 @@ int Engine::phase_dots(double *red, int *n_red) {
 }
 
 int Engine::phase_update(double *red) {
+    if (int rc = check_affinity(this, "phase_update")) return rc;
     int l0, l1;
     reorth_range(&l0, &l1);
     if (l1 - l0 <= 0) return fail("lanczos_hip_phase_update: empty range");
@@ -936,7 +955,10 @@ int Engine::phase_update(double *red) {
     return launch_finalize(norm_parts(k), norm_count, red);
 }
 
-int Engine::phase_scale(double *red) { return launch_scale(red, 1); }
+int Engine::phase_scale(double *red) {
+    if (int rc = check_affinity(this, "phase_scale")) return rc;
+    return launch_scale(red, 1);
+}
 
 // Record beta of the last deferred-normalisation iteration (its w.w partials are
 // otherwise only consumed by the next iteration's recurrence).
@@ -1175,8 +1197,21 @@ int Engine::spmv_host(const double *x_host, double *y_host) {
     return rc;
 }
 
+int Engine::make_current() {
+    HIP_TRY(hipSetDevice(device));
+    tl_current_slab = affinity_id;
+    return 0;
+}
+
+int Engine::record_event(hipEvent_t ev) {
+    if (int rc = check_affinity(this, "record_event")) return rc;
+    HIP_TRY(hipEventRecord(ev, stream));
+    return 0;
+}
+
 int Engine::enable_host_history() {
     if (h_hist) return 0;
+    if (int rc = check_affinity(this, "enable_host_history")) return rc;
     HIP_TRY(hipHostMalloc((void **)&h_hist, sizeof(double) * 2 * (size_t)hist_cap, hipHostMallocDefault));
     memset(h_hist, 0, sizeof(double) * 2 * (size_t)hist_cap);
     return 0;

@@ -123,6 +123,10 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
             goto cleanup;
         if (e->set_operator(op, op_mat) != 0) goto cleanup;
     }
+    // From here on this function touches e's stream itself (events, pinned history).  With several GPUs e
+    // is slab 0's engine and the handle's calls leave the caller's device current, not slab 0's: HIP refuses
+    // an event created or recorded under another device than its stream's.
+    if (e->make_current() != 0) goto cleanup;
     if (e->enable_host_history() != 0) goto cleanup;
     if (mg) {
         int halo = 0, over = 0;
@@ -143,6 +147,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
         printed = std::min(std::max(e->ckpt_host_k, 0), replayed);
         fprintf(stderr, "[INIT] name=resumed iterations=%d printed=%d\n", replayed, printed);
     }
+    if (e->make_current() != 0) goto cleanup;
     for (auto &ev : done)
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
             lz::fail("hipEventCreate failed");
@@ -157,10 +162,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     for (int k = 0; k < total; k++) {
         while (enq < total && enq < k + window) {
             if ((mg ? lanczos_hip_multi_step(mg) : e->enqueue_iteration()) != 0) goto cleanup;
-            if (hipEventRecord(done[(size_t)(enq % window)], e->stream) != hipSuccess) {
-                lz::fail("hipEventRecord failed");
-                goto cleanup;
-            }
+            if (e->make_current() != 0 || e->record_event(done[(size_t)(enq % window)]) != 0) goto cleanup;
             enq++;
         }
         if (k >= replayed && hipEventSynchronize(done[(size_t)(k % window)]) != hipSuccess) {
@@ -252,6 +254,7 @@ cleanup:
         reorth_steps = e->reorth_steps;
         if (mg) lanczos_hip_multi_info(mg, NULL, NULL, NULL, &iterations, &reorth_steps);
         snprintf(kernel_name, sizeof kernel_name, "%s", e->spmv_name);
+        (void)e->make_current();
         (void)hipStreamSynchronize(e->stream);
         e->harvest_profile();
         t_spmv = e->prof_ms[LANCZOS_HIP_K_SPMV] * 1e-3;

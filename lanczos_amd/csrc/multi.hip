@@ -107,6 +107,20 @@ Rccl *rccl() {
 
 int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 
+// Every entry point walks over the slabs' devices; the caller gets back the device (and the slab
+// note) it came in with, whichever slab was touched last.
+struct DeviceRestore {
+    int dev = -1, slab = -1;
+    DeviceRestore() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+        slab = lz::tl_current_slab;
+    }
+    ~DeviceRestore() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+        lz::tl_current_slab = slab;
+    }
+};
+
 // loopback all-reduce: bufs[p][i] <- sum_q bufs[q][i] for every p, slabs added in ascending order
 __global__ void __launch_bounds__(256) k_sum_slabs(double *const *__restrict__ bufs, int slabs, int count) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -146,8 +160,10 @@ struct lanczos_hip_multi {
     double last_beta = 0.0;
 
     ~lanczos_hip_multi();
+    // slab p's device becomes current (and is noted as the current slab: lz::check_affinity)
     int use(int p) const {
         if (hipSetDevice(dev[(size_t)p]) != hipSuccess) return lz::fail("hipSetDevice(%d) failed", dev[(size_t)p]);
+        lz::tl_current_slab = p;
         return 0;
     }
     double *vec(int p, int j) const {
@@ -347,6 +363,7 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
         in_lo[(size_t)p] = first_in;
         in_hi[(size_t)p] = end_in;
         M_TRY(lz::Engine::create(&eng[(size_t)p], nl, cnt, head.data(), cols.data(), va + e0, max_iter, &o));
+        eng[(size_t)p]->affinity_id = p;
         if (halo && !eng[(size_t)p]->can_split_product()) all_split = false;
     }
     overlap = all_split && P > 1 && !(getenv("LANCZOS_HIP_MULTI_NO_OVERLAP") && atoi(getenv("LANCZOS_HIP_MULTI_NO_OVERLAP")));
@@ -637,6 +654,7 @@ int lanczos_hip_multi_create(lanczos_hip_multi **out, int ngpu, const int *devic
     *out = nullptr;
     lanczos_hip_multi *m = new (std::nothrow) lanczos_hip_multi();
     if (!m) return lz::fail("lanczos_hip_multi_create: out of host memory");
+    DeviceRestore keep;
     const int rc = m->build(ngpu, devices, n, nnz, row_head_indexes, column_index, values, max_iter, opt, flags);
     if (rc) {
         delete m;
@@ -647,11 +665,15 @@ int lanczos_hip_multi_create(lanczos_hip_multi **out, int ngpu, const int *devic
     });
 }
 
-void lanczos_hip_multi_destroy(lanczos_hip_multi *m) { delete m; }
+void lanczos_hip_multi_destroy(lanczos_hip_multi *m) {
+    DeviceRestore keep;
+    delete m;
+}
 
 int lanczos_hip_multi_set_start(lanczos_hip_multi *m, const double *v0_host) {
     return lz::guarded("lanczos_hip_multi_set_start", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_set_start: NULL handle");
+    DeviceRestore keep;
     return m->set_start(v0_host);
     });
 }
@@ -666,6 +688,7 @@ int lanczos_hip_multi_set_start_seed(lanczos_hip_multi *m, uint64_t seed) {
         return lz::fail("lanczos_hip_multi_set_start_seed: out of host memory");
     }
     lanczos_hip_gaussian_fill(seed, 0, m->n, v.data());
+    DeviceRestore keep;
     return m->set_start(v.data());
     });
 }
@@ -673,6 +696,7 @@ int lanczos_hip_multi_set_start_seed(lanczos_hip_multi *m, uint64_t seed) {
 int lanczos_hip_multi_run(lanczos_hip_multi *m, int steps, double *alpha_out, double *beta_out) {
     return lz::guarded("lanczos_hip_multi_run", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_run: NULL handle");
+    DeviceRestore keep;
     return m->run(steps, alpha_out, beta_out);
     });
 }
@@ -680,6 +704,7 @@ int lanczos_hip_multi_run(lanczos_hip_multi *m, int steps, double *alpha_out, do
 int lanczos_hip_multi_step(lanczos_hip_multi *m) {
     return lz::guarded("lanczos_hip_multi_step", [&]() -> int {
     if (!m) return lz::fail("lanczos_hip_multi_step: NULL handle");
+    DeviceRestore keep;
     return m->step(true);
     });
 }

@@ -22,6 +22,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _slab_affinity_checked(monkeypatch):
+    """Every call into a slab's engine is checked against the slab the driver made current: on this
+    one-GPU box all slabs share a device, so HIP itself would accept a call made under the wrong one."""
+    monkeypatch.setenv("LANCZOS_HIP_CHECK_AFFINITY", "1")
+
+
 def single(a, v0, steps, reorth):
     with la.Engine(a, steps + 1, reorth=reorth) as e:
         e.set_start(v0)
@@ -175,6 +182,22 @@ def _dropin(a, nth, max_iter, thr, env):
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][0][7:])
     return res, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("reorth", ["full", "none", "selective"])
+def test_dropin_touches_slab_zero_only_with_its_device_current(gpu, reorth):
+    """The drop-in's own host loop records events on slab 0's stream between calls that walk over all
+    slabs' devices.  With three slabs and the affinity check on, an event created or recorded while
+    another slab is current (what HIP refuses on a node with one GPU per slab) ends the run with a message."""
+    a = la.synth_laplacian(3, 24)
+    v0 = la.gaussian_fill(123456789, 0, a.dimension)
+    max_iter = 26 if reorth == "none" else 41   # without reorthogonalisation only the first steps are determined
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, max_iter, 0.0, reorth)
+    res, out, err = _dropin(a, 4, max_iter, 0.0, {"LANCZOS_HIP_NGPU": "3", "LANCZOS_HIP_MULTI_LOOPBACK": "1",
+                                                  "LANCZOS_HIP_REORTH": reorth, "LANCZOS_HIP_CHECK_AFFINITY": "1"})
+    assert "is current" not in out, out[-500:]
+    assert res["rc"] == 0 and f"Reached max iterations ({max_iter})" in out
+    assert rel_err(res["eig"], o.eigenvalues) < 1e-10, reorth
 
 
 def test_dropin_honours_ngpu(gpu):
