@@ -35,10 +35,35 @@ WORKLOADS = {
 }
 
 
+# Rate at which an XCD's L2 was measured to serve whole 128-byte lines to gathers, chip-wide
+# (hardware guide, "Indexed rows: gather into LDS": 16.8-18.8 TB/s of 128-byte lines)
+L2_GATHER_LINES_PER_S = (16.8e12 / 128, 18.8e12 / 128)
+
+
 def algorithmic_bytes(n: int, nnz: int) -> dict:
+    """The shared per-iteration figures on the CRS format (4-byte columns): each operand read once, each
+    result written once.  `vec_charged` = alpha dot 16 n + recurrence 32 n + scaling 16 n, what a step
+    with separate kernels would move; `vec_moved` = the 32 n the fused deferred-normalisation
+    recurrence of the SpMV + vector step really moves (alpha comes out of the SpMV, no scaling pass)."""
     wp = 4 if nnz < 2**31 else 8
     b_spmv = 12 * nnz + wp * (n + 1) + 16 * n
-    return {"spmv": b_spmv, "vec": 64 * n, "iter": b_spmv + 64 * n}
+    return {"spmv": b_spmv, "vec_charged": 64 * n, "vec_moved": 32 * n, "iter_charged": b_spmv + 64 * n,
+            "iter_moved": b_spmv + 32 * n}
+
+
+def gather_ceiling(kind: str, nnz: int, spmv_seconds: float):
+    """The gather-bound SpMV forms against the L2s' measured line rate instead of the HBM roofline:
+    L2 requests per SpMV = nnz x the requests-per-entry ratio that the PMC passes counted for this
+    form (TCC_REQ_sum, profiles/gather_requests.json), over the SpMV's time.  None without a record."""
+    try:
+        rec = json.load(open(os.path.join(HERE, "profiles", "gather_requests.json")))[kind]
+    except (OSError, ValueError, KeyError):
+        return None
+    req_s = rec["l2_requests_per_entry"] * nnz / spmv_seconds
+    lo, hi = L2_GATHER_LINES_PER_S
+    return {"l2_requests_per_entry": rec["l2_requests_per_entry"], "counted_on": rec["counted_on"],
+            "l2_requests_per_s": req_s, "l2_line_rate_measured_per_s": [lo, hi],
+            "frac_of_l2_line_rate": req_s / hi, "frac_of_l2_line_rate_low_end": min(req_s / lo, 1.0)}
 
 
 def parse_args():
@@ -181,12 +206,15 @@ def random_symmetric_section(la, torch, rows: int, steps: int = 100) -> dict:
         "steps": steps,
         "iters_per_s": steps / dt,
         "ms_per_iter": dt / steps * 1e3,
-        "algorithmic_bytes_per_iter": b["iter"],
-        "frac_of_hbm_peak": b["iter"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
+        # CRS algorithmic bytes + the 32 n the recurrence moves: what the step must at least move
+        "algorithmic_bytes_per_iter": b["iter_moved"],
+        "frac_of_hbm_peak": b["iter_moved"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
         "spmv_kernel": name,
         "spmv_avg_ms": prof["spmv"]["ms"] / steps,
         "spmv_GBps": spmv_gbps,
         "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
+        # one L2 request per gather: the ceiling this kernel runs against
+        "gather_ceiling": gather_ceiling("random_symmetric", nnz, prof["spmv"]["ms"] * 1e-3 / steps),
         "generate_s": t_gen,
     }
 
@@ -195,8 +223,7 @@ def power_law_section(la, torch, scale: int, steps: int = 50, block_steps: int =
     """Power-law rows: the graph Laplacian of an R-MAT graph (edge factor 16, a/b/c = 0.57/0.19/0.19),
     drawn on the GPU.  The SpMV + vector step of the single-vector path, and block steps of the 16-column
     variant (fp64 matrix-core reorthogonalisation) on the same matrix."""
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
-    from matrices import rmat_laplacian_gpu
+    from lanczos_amd.synth_gpu import rmat_laplacian_gpu
     t0 = time.perf_counter()
     a = la.CrsMatrix(*rmat_laplacian_gpu(scale))
     t_gen = time.perf_counter() - t0
@@ -219,11 +246,12 @@ def power_law_section(la, torch, scale: int, steps: int = 50, block_steps: int =
         "steps": steps,
         "iters_per_s": steps / dt,
         "ms_per_iter": dt / steps * 1e3,
-        "algorithmic_bytes_per_iter": b["iter"],
-        "frac_of_hbm_peak": b["iter"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
+        "algorithmic_bytes_per_iter": b["iter_moved"],
+        "frac_of_hbm_peak": b["iter_moved"] * steps / dt / 1e9 / HBM_PEAK_GBPS,
         "spmv_kernel": name,
         "spmv_avg_ms": prof["spmv"]["ms"] / steps,
         "spmv_G_entries_per_s": nnz * steps / (prof["spmv"]["ms"] * 1e-3) / 1e9,
+        "gather_ceiling": gather_ceiling("power_law_graph", nnz, prof["spmv"]["ms"] * 1e-3 / steps),
         "generate_s": t_gen,
     }
     if block_steps > 0:
@@ -265,17 +293,21 @@ def big_laplacian_section(la, torch, N: int, steps: int = 100) -> dict:
         dt = time.perf_counter() - t0
         prof = e.profile()
         name = e.spmv_name
-    fmt_iter = prof["spmv"]["bytes"] / steps + 64.0 * n
+    fmt_iter = prof["spmv"]["bytes"] / steps + 32.0 * n   # the format's SpMV bytes + the recurrence's 32 n
     return {
         "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), SpMV + vector step, reorth=none",
         "steps": steps,
         "iters_per_s": steps / dt,
         "ms_per_iter": dt / steps * 1e3,
         "spmv_kernel": name,
-        "format_bytes_per_iter": fmt_iter,
+        "bytes_moved_per_iter": fmt_iter,
         "frac_of_hbm_peak": fmt_iter * steps / dt / 1e9 / HBM_PEAK_GBPS,
-        "crs_algorithmic_bytes_per_iter": b["iter"],
-        "crs_bytes_over_time_GBps": b["iter"] * steps / dt / 1e9,
+        "kernel_ms_per_iter": {k: v["ms"] / steps for k, v in prof.items()},
+        "kernel_GBps": {k: v["bytes"] / (v["ms"] * 1e-3) / 1e9 for k, v in prof.items() if v["ms"] > 0},
+        # for comparison with a solver on the CRS arrays: its charged bytes over this run's time (a rate in
+        # another format's bytes, not a fraction of anything this run moved)
+        "crs_charged_bytes_per_iter": b["iter_charged"],
+        "crs_charged_bytes_over_time_GBps": b["iter_charged"] * steps / dt / 1e9,
         "spmv_avg_ms": prof["spmv"]["ms"] / steps,
         "setup_s": {"generate": t_gen, "upload": t_up},
     }
@@ -359,34 +391,39 @@ def single_gpu(args, keeper=None) -> dict:
         p2 = e2.profile()
         name = e2.spmv_name
         e2.close()
-        # bytes of the matrix format in use: CRS = 12 nnz + 4 (n + 1) + 16 n; dictionary = 2 n + 16 n;
-        # the vector part is charged 64 n either way
+        # bytes this run moves per iteration: the SpMV's bytes in the matrix format in use (CRS = 12 nnz +
+        # 4 (n + 1) + 16 n; CRS values + pattern numbers = 8 nnz + 4 (n + 1) + 2 n + 16 n; dictionary = 2 n + 16 n)
+        # plus the 32 n of the deferred-normalisation recurrence (alpha's partials come out of the SpMV,
+        # there is no scaling pass)
         fmt_spmv = p2["spmv"]["bytes"] / S
-        fmt_iter = fmt_spmv + 64.0 * n
+        moved = fmt_spmv + 32.0 * n
         spmv_gb = p2["spmv"]["bytes"] / (p2["spmv"]["ms"] * 1e-3) / 1e9
-        return {
+        plain_crs = not (name.startswith("dict") or (name.startswith("rows") and name.endswith("p")))
+        rec = {
             "iters_per_s": S / dt2,
             "ms_per_iter": dt2 / S * 1e3,
             "spmv_kernel": name,
             "matrix_format": "row-pattern dictionary" if name.startswith("dict") else
                              "CRS values and row offsets + column-offset patterns" if name.startswith("rows") and name.endswith("p")
                              else "CRS",
-            "format_bytes_per_iter": fmt_iter,
-            "achieved_GBps": fmt_iter * S / dt2 / 1e9,
-            "frac_of_hbm_peak": fmt_iter * S / dt2 / 1e9 / HBM_PEAK_GBPS,
-            "crs_algorithmic_bytes_per_iter": bytes_["iter"],
-            "crs_bytes_over_time_GBps": bytes_["iter"] * S / dt2 / 1e9,
+            "bytes_moved_per_iter": moved,
+            "achieved_GBps": moved * S / dt2 / 1e9,
+            "frac_of_hbm_peak": moved * S / dt2 / 1e9 / HBM_PEAK_GBPS,
             "spmv_avg_ms": p2["spmv"]["ms"] / S,
             "spmv_GBps": spmv_gb,
             "spmv_frac_of_hbm_peak": spmv_gb / HBM_PEAK_GBPS,
             "kernel_ms_per_iter": {k: v["ms"] / S for k, v in p2.items()},
-            # the vector part two ways: the shared figure charges 64 n per step (alpha dot 16 n, recurrence
-            # 32 n, scaling 16 n); the deferred-normalisation recurrence this mode runs moves 32 n
-            "bytes_charged": fmt_spmv + 64.0 * n,
-            "bytes_moved": fmt_spmv + 32.0 * n,
-            "frac_of_hbm_peak_charged": (fmt_spmv + 64.0 * n) * S / dt2 / 1e9 / HBM_PEAK_GBPS,
-            "frac_of_hbm_peak_moved": (fmt_spmv + 32.0 * n) * S / dt2 / 1e9 / HBM_PEAK_GBPS,
+            "kernel_GBps": {k: v["bytes"] / (v["ms"] * 1e-3) / 1e9 for k, v in p2.items() if v["ms"] > 0},
+            # a rate in another format's bytes (what a solver on the CRS arrays with separate vector kernels would
+            # be charged, B_spmv + 64 n, over this run's time): for comparisons across formats, not a fraction
+            "crs_charged_bytes_per_iter": bytes_["iter_charged"],
+            "crs_charged_bytes_over_time_GBps": bytes_["iter_charged"] * S / dt2 / 1e9,
         }
+        if plain_crs:
+            # on the CRS arrays themselves the charged figure is this kernel's own format: B_spmv + 64 n
+            # (alpha dot, recurrence, scaling as separate passes) against the B_spmv + 32 n it moves
+            rec["crs_charged_frac_of_hbm_peak"] = bytes_["iter_charged"] * S / dt2 / 1e9 / HBM_PEAK_GBPS
+        return rec
 
     sv_crs_planes = None
     if args.main_only:
@@ -423,7 +460,10 @@ def single_gpu(args, keeper=None) -> dict:
             "parallelism": "1 GPU",
         },
         "roofline": roofline_from_profile(prof),
-        "spmv_hbm_GBps": sv_crs["spmv_GBps"],
+        # the SpMV kernel of the timed run, in the bytes of the format it reads
+        "spmv_hbm_GBps": (prof["spmv"]["bytes"] / (prof["spmv"]["ms"] * 1e-3) / 1e9) if prof["spmv"]["ms"] > 0 else None,
+        "spmv_hbm_kernel": spmv_name_main,
+        "spmv_hbm_GBps_plain_crs_kernel": sv_crs["spmv_GBps"],
         "spmv_vector_step": sv,
         "spmv_vector_step_crs": sv_crs,
         "spmv_vector_step_crs_values": sv_crs_planes,
@@ -511,21 +551,25 @@ def single_gpu(args, keeper=None) -> dict:
 
     def sec_cpu():
         cb = cpu_baseline(a, v0, args.cpu_steps)
-        s = min(cb["steps"], K)
-        # GPU rate over the same first s iterations (its cost per step also grows with k)
+        s = cb["steps"]
+        # the SAME sample on the GPU: a run of its own over the first s iterations (the cost of a step grows
+        # with k on both sides), its rate, and the agreement of the two runs
         eng3 = la.Engine(a, s + 1, reorth=args.reorth, spmv=args.spmv)
         eng3.set_start(v0)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        eng3.run(s)
+        a3, b3 = eng3.run(s)
         torch.cuda.synchronize()
         cb["gpu_same_sample_value"] = s / (time.perf_counter() - t3)
         eng3.close()
-        # the same sample on the GPU, and the agreement of the two alpha/beta sequences
+        ca, cbeta, cr = np.array(cb["alpha"][:s]), np.array(cb["beta"][:s]), np.array(cb["ritz"])
         cb["gpu_same_sample_rel_err"] = {
-            "alpha": float(np.max(np.abs(alpha[:s] - np.array(cb["alpha"][:s])) / np.abs(np.array(cb["alpha"][:s])))),
-            "beta": float(np.max(np.abs(beta[:s] - np.array(cb["beta"][:s])) / np.abs(np.array(cb["beta"][:s])))),
+            "steps": s,
+            "alpha": float(np.max(np.abs(a3 - ca) / np.abs(ca))),
+            "beta": float(np.max(np.abs(b3 - cbeta) / np.abs(cbeta))),
         }
+        m = min(4, s)
+        cb["ritz_rel_err"] = float(np.max(np.abs(la.ritz_values(a3, b3, s, m) - cr[:m]) / np.abs(cr[:m])))
         del cb["alpha"], cb["beta"], cb["ritz"]
         out["cpu_baseline"] = cb
 

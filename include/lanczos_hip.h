@@ -317,7 +317,10 @@ int lanczos_hip_spmv(lanczos_hip_engine *e, const double *x_host, double *y_host
  * device image, one copy per GPU, held until the process ends.  Limits: on the merge SpMV at most
  * 67 108 864 entries, on the tiled SpMV at most 262 144 rows of split-block pieces (32 pieces of 8192 rows), otherwise none beyond
  * the engine's own; beyond them the call fails with a message and launches nothing.  Calls on the same
- * GPU share the array: two that overlap in time (different streams or threads) race on it.
+ * GPU share the array: two that overlap in time (different streams or threads) race on it, and the
+ * engine itself must not be used from another thread while the call runs (its scratch pointers are
+ * swapped for the fixed array until the launch is enqueued).  Refused on an engine whose operator is
+ * a host function (lanczos_hip_set_operator): there is no device product to launch.
  */
 int lanczos_hip_spmv_noalloc(lanczos_hip_engine *e, const double *x_dev, double *y_dev, double *dot_dev);
 

@@ -14,13 +14,14 @@
 namespace {
 
 struct Header {
-    char magic[8];        // "LZCKPT3"
+    char magic[8];        // "LZCKPT4"
     int64_t n, ldv, nnz;
     uint64_t matrix_print;  // fingerprint of the device CRS arrays (row offsets, columns, values)
     int32_t reorth, max_iter, nvec, k, lazy, lazy_flushed_k, alpha_count, norm_count, max_blocks, hist_cap;
     int32_t reorth_steps, tracker_doubles, spmv_kind, host_k;
+    char spmv_name[32];   // the SpMV form in full (kind, pattern count, plane walk): the saved partial sums are its
 };
-const char kMagic[8] = "LZCKPT3";
+const char kMagic[8] = "LZCKPT4";
 
 __device__ __forceinline__ uint64_t mix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ULL;
@@ -105,6 +106,8 @@ extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *p
     if (!e || !path) return lz::fail("lanczos_hip_checkpoint_save: NULL argument");
     if (!e->started) return lz::fail("lanczos_hip_checkpoint_save: no run to save");
     if (e->slab) return lz::fail("lanczos_hip_checkpoint_save: not available on a row-partitioned engine");
+    if (e->ext_matvec)  // the matrix fingerprint is what ties a file to its operator; a host function has none
+        return lz::fail("lanczos_hip_checkpoint_save: not available for an operator supplied as a host function");
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
         return lz::fail("lanczos_hip_checkpoint_save: device not reachable");
     Header h;
@@ -117,6 +120,7 @@ extern "C" int lanczos_hip_checkpoint_save(lanczos_hip_engine *eh, const char *p
     h.ldv = e->ldv;
     h.nnz = e->nnz;
     h.spmv_kind = e->spmv_kind;
+    snprintf(h.spmv_name, sizeof h.spmv_name, "%s", e->spmv_name);
     h.host_k = e->ckpt_host_k >= 0 ? std::min(e->ckpt_host_k, e->k) : e->k;
     h.reorth = e->reorth;
     h.max_iter = e->max_iter;
@@ -159,6 +163,8 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
     lz::Engine *e = reinterpret_cast<lz::Engine *>(eh);
     if (!e || !path) return lz::fail("lanczos_hip_checkpoint_load: NULL argument");
     if (e->slab) return lz::fail("lanczos_hip_checkpoint_load: not available on a row-partitioned engine");
+    if (e->ext_matvec)
+        return lz::fail("lanczos_hip_checkpoint_load: not available for an operator supplied as a host function");
     if (hipSetDevice(e->device) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
         return lz::fail("lanczos_hip_checkpoint_load: device not reachable");
     uint64_t print = 0;
@@ -179,12 +185,13 @@ extern "C" int lanczos_hip_checkpoint_load(lanczos_hip_engine *eh, const char *p
                         "(n=%lld, reorth=%d, max_iter=%d)", (long long)h.n, h.reorth, h.k, (long long)e->n, e->reorth,
                         e->max_iter);
     }
-    if (h.nnz != e->nnz || h.matrix_print != print || h.spmv_kind != e->spmv_kind) {
+    h.spmv_name[sizeof h.spmv_name - 1] = 0;
+    if (h.nnz != e->nnz || h.matrix_print != print || h.spmv_kind != e->spmv_kind || strcmp(h.spmv_name, e->spmv_name) != 0) {
         fclose(fp);
-        return lz::fail("lanczos_hip_checkpoint_load: the checkpoint was written for another matrix (nnz=%lld, fingerprint "
-                        "%016llx, SpMV form %d; this engine: nnz=%lld, %016llx, form %d)", (long long)h.nnz,
-                        (unsigned long long)h.matrix_print, h.spmv_kind, (long long)e->nnz, (unsigned long long)print,
-                        e->spmv_kind);
+        return lz::fail("lanczos_hip_checkpoint_load: the checkpoint was written for another matrix or SpMV form (nnz=%lld, "
+                        "fingerprint %016llx, form %s; this engine: nnz=%lld, %016llx, form %s)", (long long)h.nnz,
+                        (unsigned long long)h.matrix_print, h.spmv_name, (long long)e->nnz, (unsigned long long)print,
+                        e->spmv_name);
     }
     // counts that become loop bounds and buffer sizes: inside what this engine allocated
     const int64_t tracker_max = 64 + 8 * (int64_t)std::max(h.max_iter, 2);

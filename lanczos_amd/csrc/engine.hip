@@ -407,9 +407,15 @@ int Engine::choose_spmv(int requested) {
     if (spmv_kind == LANCZOS_HIP_SPMV_ROWS && !slab && nnz > 0) {
         // stencil-like rows whose values do not repeat: their column offsets may (a grid with variable
         // coefficients); the product then walks the grid's planes with the values read from the CRS array
-        if (int rc = build_dict(false)) return rc;
-        pdict = pdict_usable();
-        if (!pdict) free_dict();
+        // (an optimisation only: when the dictionary's temporaries, about 3 x 8 n bytes beside the sort's,
+        // do not fit, the plain row-wise kernel runs)
+        if (build_dict(false) != 0) {
+            (void)hipGetLastError();
+            free_dict();
+        } else {
+            pdict = pdict_usable();
+            if (!pdict) free_dict();
+        }
     }
     if (spmv_kind == LANCZOS_HIP_SPMV_MERGE)
         snprintf(spmv_name, sizeof(spmv_name), "merge%s", rp64 ? "_rp64" : "");

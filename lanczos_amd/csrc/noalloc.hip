@@ -7,6 +7,10 @@
 // capture, a serving loop, a harness that forbids hipMalloc -- get the same kernels here with that
 // scratch memory in a fixed array that lives in the library's device image: kScratchBytes per GPU
 // the library runs on, held until the process ends.
+//
+// For the duration of the call the engine's own scratch pointers are swapped for the fixed array, so
+// the engine must not be used from another thread meanwhile; and every call on a GPU shares that
+// GPU's array, so calls that overlap on one GPU (two engines, two streams) race.
 #include <mutex>
 
 #include "engine.h"
@@ -68,6 +72,9 @@ namespace lz {
 
 int Engine::spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev) {
     if (hipSetDevice(device) != hipSuccess) return fail("lanczos_hip_spmv_noalloc: hipSetDevice(%d) failed", device);
+    if (ext_matvec)  // the engine holds an empty matrix then: the product is the caller's host function
+        return fail("lanczos_hip_spmv_noalloc: this engine's operator is a host function (lanczos_hip_set_operator); "
+                    "there is no device product to launch");
     if (2 * max_blocks > kMaxParts)
         return fail("lanczos_hip_spmv_noalloc: %d workgroups leave more partial sums than the fixed scratch holds (%d)",
                     2 * max_blocks, kMaxParts);

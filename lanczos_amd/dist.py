@@ -594,7 +594,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
                 "frac": achieved / hbm_peak, "traffic": None, "launches": p["launches"],
                 "note": "rank 0's slab; per-GPU figure",
             },
-            "algorithmic_bytes_per_iter_no_reorth": bytes_["iter"],
+            "crs_charged_bytes_per_iter_no_reorth": bytes_["iter_charged"],
             "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
             "ritz_lowest4": [float(x) for x in ritz],
         }
@@ -602,8 +602,15 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
     # prints the last line it was given when this one ends, however it ends).  What follows are secondary
     # sections; should one of them hang on some rank (they have never run on more than one GPU), every rank
     # leaves after a deadline, so the run still reports its metric.
+    import tempfile
     import threading
-    state = {"done": False}
+    state = {"done": False, "section": "primary"}
+    ctl = dist.new_group(backend="gloo")     # host-side agreement between the ranks: no kernel spins on a GPU for it
+    # one node by contract: a file every rank can see calls the secondary sections off for all of them
+    abort_path = os.path.join(tempfile.gettempdir(), f"lanczos_bench_abort_{os.environ.get('MASTER_PORT', '0')}")
+    if rank == 0 and os.path.exists(abort_path):
+        os.remove(abort_path)
+    dist.barrier(group=ctl)
 
     def publish():
         if rank == 0 and out is not None and keeper is not None:
@@ -611,27 +618,62 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
 
     publish()
 
-    def _bail():
+    def _leave(reason):
+        """Ends this rank from whichever thread notices that the secondary sections cannot go on.  Rank 0's
+        keeper still prints the primary line (with the reason in it); the exit code says that the run did
+        not finish."""
         if state["done"]:
             return
         if rank == 0 and out is not None:
-            out["secondary_sections"] = "abandoned at the deadline"
+            out["secondary_sections"] = reason
             publish()
-        os._exit(0)
+        os._exit(3)
 
     deadline = float(os.environ.get("LANCZOS_BENCH_SECONDARY_DEADLINE_S", "420"))
-    timer = threading.Timer(deadline, _bail)
+    timer = threading.Timer(deadline, lambda: _leave(f"abandoned at the {deadline:.0f} s deadline in section "
+                                                     f"{state['section']}"))
     timer.daemon = True
     timer.start()
 
+    def _watch():
+        while not state["done"]:
+            if os.path.exists(abort_path):
+                try:
+                    why = open(abort_path).read()
+                except OSError:
+                    why = "called off by another rank"
+                _leave(f"abandoned in section {state['section']}: {why}"[:400])
+            time.sleep(0.5)
+
+    watcher = threading.Thread(target=_watch, daemon=True)
+    watcher.start()
+    grace = float(os.environ.get("LANCZOS_BENCH_SECTION_GRACE_S", "30"))
+
     def section(name, fn):
-        """A secondary section; an error is recorded in the line instead of ending the run.  Errors that
-        come from the configuration are the same on every rank, so the ranks stay in step."""
+        """A secondary section.  An error is recorded in the line instead of ending the run, and the ranks
+        agree on it (a sum over the host-side group) so that they go on in step.  A rank that failed while
+        the others are still inside one of the section's collectives would wait for that agreement for
+        ever: it gives them `grace` seconds, then calls the remaining sections off for every rank."""
+        state["section"] = name
+        err = None
         try:
             fn()
         except Exception as exc:  # noqa: BLE001
-            if rank == 0:
-                out.setdefault("section_errors", {})[name] = f"{type(exc).__name__}: {exc}"[:300]
+            err = f"{type(exc).__name__}: {exc}"[:300]
+        call_off = None
+        if err is not None:
+            def _call_off():
+                with open(abort_path, "w") as f:
+                    f.write(f"rank {rank} failed ({err}); the other ranks did not leave the section within {grace:.0f} s")
+            call_off = threading.Timer(grace, _call_off)
+            call_off.daemon = True
+            call_off.start()
+        failed = torch.tensor([1 if err is not None else 0], dtype=torch.int64)
+        dist.all_reduce(failed, group=ctl)
+        if call_off is not None:
+            call_off.cancel()
+        if int(failed.item()) and rank == 0:
+            out.setdefault("section_errors", {})[name] = err or f"{int(failed.item())} of {world} ranks failed"
         import gc
         gc.collect()
         torch.cuda.empty_cache()
@@ -649,16 +691,17 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
         p2 = r2.engine.e.profile()
         if rank == 0:
             b = algorithmic_bytes(n, nnz)
-            # bytes of the matrix format in use on rank 0's slab (CRS or row-pattern dictionary), times the ranks
-            fmt_iter = (p2["spmv"]["bytes"] / steps2 + 64.0 * (bounds[1] - bounds[0])) * world
+            # bytes moved: the SpMV in the matrix format in use on rank 0's slab (CRS or row-pattern dictionary)
+            # plus the 32 n of the deferred-normalisation recurrence, times the ranks
+            fmt_iter = (p2["spmv"]["bytes"] / steps2 + 32.0 * (bounds[1] - bounds[0])) * world
             out["spmv_vector_step"] = {
                 "iters_per_s": steps2 / dt2,
                 "ms_per_iter": dt2 / steps2 * 1e3,
                 "spmv_kernel": r2.engine.e.spmv_name,
-                "format_bytes_per_iter": fmt_iter,
+                "bytes_moved_per_iter": fmt_iter,
                 "frac_of_hbm_peak": fmt_iter * steps2 / dt2 / 1e9 / (hbm_peak * world),
-                "crs_algorithmic_bytes_per_iter": b["iter"],
-                "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt2 / 1e9,
+                "crs_charged_bytes_per_iter": b["iter_charged"],
+                "crs_charged_bytes_over_time_GBps": b["iter_charged"] * steps2 / dt2 / 1e9,
                 "spmv_avg_ms_rank0": p2["spmv"]["ms"] / steps2,
                 "exchange": r2.plan.mode,
                 "all_reduces_per_step": 1 if r2.lazy else 2,
@@ -689,9 +732,10 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
                 "iters_per_s": steps2 / dt4,
                 "ms_per_iter": dt4 / steps2 * 1e3,
                 "spmv_kernel": r4.engine.e.spmv_name,
-                "format_bytes_per_iter": (p4["spmv"]["bytes"] / steps2 + 64.0 * (bb[1] - bb[0])) * world,
-                "crs_algorithmic_bytes_per_iter": b["iter"],
-                "crs_bytes_over_time_GBps": b["iter"] * steps2 / dt4 / 1e9,
+                "bytes_moved_per_iter": (p4["spmv"]["bytes"] / steps2 + 32.0 * (bb[1] - bb[0])) * world,
+                "frac_of_hbm_peak": (p4["spmv"]["bytes"] / steps2 + 32.0 * (bb[1] - bb[0])) * steps2 / dt4 / 1e9 / hbm_peak,
+                "crs_charged_bytes_per_iter": b["iter_charged"],
+                "crs_charged_bytes_over_time_GBps": b["iter_charged"] * steps2 / dt4 / 1e9,
                 "spmv_avg_ms_rank0": p4["spmv"]["ms"] / steps2,
                 "exchange": r4.plan.mode,
                 "exchange_overlapped_with_product": r4.interior is not None,
@@ -720,8 +764,8 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
                 "steps": steps2,
                 "iters_per_s": steps2 / dt3,
                 "ms_per_iter": dt3 / steps2 * 1e3,
-                "algorithmic_bytes_per_iter": b["iter"],
-                "frac_of_hbm_peak": b["iter"] * steps2 / dt3 / 1e9 / (hbm_peak * world),
+                "algorithmic_bytes_per_iter": b["iter_moved"],
+                "frac_of_hbm_peak": b["iter_moved"] * steps2 / dt3 / 1e9 / (hbm_peak * world),
                 "spmv_avg_ms_rank0": p3["spmv"]["ms"] / steps2,
                 "exchange": r3.plan.mode,
             }
@@ -746,7 +790,7 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
         # node through the library's own RCCL calls (lanczos_hip_multi_*, what LANCZOS_HIP_NGPU gives the
         # C driver), while the other ranks wait on the host.  Same matrix, start vector and step counts as
         # the primary figure.
-        gl = dist.new_group(backend="gloo")          # a host-side barrier: no kernel spins on the waiting GPUs
+        gl = ctl                                     # a host-side barrier: no kernel spins on the waiting GPUs
         if rank == 0:
             try:
                 full = la.synth_laplacian(d, N)

@@ -13,12 +13,22 @@
  *
  * Pinning: the COO->CRS build, the triplet parser and both matvecs are checked
  * byte-for-byte against the reference's own crs.c / coo.c compiled as they lie
- * (oracle/_ref, see oracle/Makefile).  The Lanczos loop is pinned by the
- * reference's recorded Ritz values for fixed start vectors (tests/golden/
- * reference_known_answers.json) and by closed-form Laplacian spectra.  The dense
- * eigen-solve of the reference is Intel MKL LAPACKE_dsyevr_work (third party,
- * version unpinned by the reference's Makefile:4, not vendored); it is restated
- * here as an implicit QL iteration and checked against LAPACK dsyevr/dstebz.
+ * (oracle/_ref, see oracle/Makefile).
+ *
+ * THE LANCZOS LOOP (orc_lanczos_*) IS "PARITY UNPINNED": the reference holds no
+ * test, fixture or recorded output for it, and its loop cannot be rebuilt in
+ * this image (src/util.c:7 includes mkl_lapacke.h, which is absent, and
+ * src/lanczos.c does not link without util.c).  What ties it to the reference
+ * is the line-by-line citation below and nothing a build could re-run.  Beside
+ * that there are (i) Ritz values written down once from a build of the
+ * unmodified reference that nothing in this repository regenerates
+ * (tests/golden/reference_known_answers.json: reproduced here to 1.2e-12
+ * relative) and (ii) closed-form Laplacian spectra; neither is a fixture of the
+ * reference.  The dense eigen-solve of the reference is Intel MKL
+ * LAPACKE_dsyevr_work (third party, version unpinned by the reference's
+ * Makefile:4, not vendored); it is restated here as an implicit QL iteration
+ * and checked against values the MKL 2021.4 runtime gave for the reference's
+ * arguments (tests/golden/mkl_dsyevr.json, generating script committed).
  */
 #include <ctype.h>
 #include <float.h>

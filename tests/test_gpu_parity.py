@@ -843,6 +843,43 @@ def test_lanczos_takes_a_custom_matvec_plugin(gpu):
         assert rel_err(alpha[:20], oo.alpha[:20]) < 1e-11 and rel_err(beta[:20], oo.beta[:20]) < 1e-11, reorth
 
 
+def test_a_host_operator_has_no_checkpoint_and_no_device_product(gpu, tmp_path):
+    """An engine whose operator is a host function holds an empty matrix: nothing identifies the operator
+    in a checkpoint file, and there is no device product for the entry point that allocates nothing."""
+    import torch
+    n = 4096
+    fn = la.MATVEC_FN(lambda _m, vec, dist: None)
+    empty = la.CrsMatrix(np.zeros(0), np.zeros(0, np.int64), np.zeros(n + 1, np.int64))
+    with la.Engine(empty, 11) as e:
+        e.set_operator(fn)
+        e.set_start(np.ones(n))
+        with pytest.raises(la.LanczosHipError, match="host function"):
+            e.checkpoint_save(str(tmp_path / "op.ckpt"))
+        x = torch.ones(n, dtype=torch.float64, device="cuda")
+        y = torch.full((n,), 7.0, dtype=torch.float64, device="cuda")
+        with pytest.raises(la.LanczosHipError, match="host function"):
+            e.spmv_noalloc(x.data_ptr(), y.data_ptr())
+        torch.cuda.synchronize()
+        assert bool((y == 7.0).all())          # nothing was launched
+
+
+def test_checkpoint_of_another_spmv_form_is_refused(gpu, tmp_path):
+    """The saved partial sums belong to the SpMV form that left them: a file written under the dictionary
+    form is not continued by an engine of the same matrix on the row-wise form."""
+    a = la.synth_laplacian(3, 20)
+    path = str(tmp_path / "form.ckpt")
+    with la.Engine(a, 21, spmv="dict") as e:
+        e.set_start_seed(3)
+        e.run(5)
+        e.checkpoint_save(path)
+    with la.Engine(a, 21, spmv="stream") as e:
+        with pytest.raises(la.LanczosHipError, match="another matrix or SpMV form"):
+            e.checkpoint_load(path)
+    with la.Engine(a, 21, spmv="dict") as e:
+        e.checkpoint_load(path)
+        assert e.iterations == 5
+
+
 def test_c_program_with_a_matrix_free_plugin(gpu):
     """lanczos_amd/bin/plugin_demo: a C program whose only operator is a function (2-D Laplacian applied
     matrix-free) calls lanczos() of liblanczos_host; values against the oracle on the assembled matrix."""
