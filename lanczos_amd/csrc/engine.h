@@ -178,6 +178,7 @@ struct Engine {
     // basis slot of Lanczos vector j (a ring of 3 when nothing older is needed)
     double *vec(int j) const { return d_V + (size_t)(reorth == LANCZOS_HIP_REORTH_NONE ? j % 3 : j) * (size_t)ldv; }
     int vec_blocks() const;
+    int recur_blocks() const;
     int tile_blocks() const;
     double spmv_bytes() const;
 

@@ -516,6 +516,18 @@ int Engine::vec_blocks() const {
     return (int)std::min<int64_t>(max_blocks, (n2 + kBlock - 1) / kBlock);
 }
 
+// grid of the recurrence and scaling kernels: whole tiles, two workgroups per CU (512^3, k_recur_lazy with
+// 2 / 4 / 8 per CU: 0.741 / 0.785 / 0.766 ms; LANCZOS_HIP_VEC_WG_PER_CU for measurements)
+int Engine::recur_blocks() const {
+    static const int per_cu = [] {
+        const char *s = getenv("LANCZOS_HIP_VEC_WG_PER_CU");
+        const int v = s ? atoi(s) : 0;
+        return v >= 1 && v <= 8 ? v : 2;
+    }();
+    const int64_t tiles = (npad / 2) / kTileV2;
+    return (int)std::min<int64_t>((int64_t)cus * per_cu, std::max<int64_t>(tiles, 1));
+}
+
 int Engine::tile_blocks() const {
     // 4 workgroups per CU: measured best for the basis-streaming kernels
     const int64_t tiles = (npad / 2) / kTileV2;
@@ -561,7 +573,12 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, do
         *nparts = blocks;
         // LANCZOS_HIP_ROWS_MASK=0: the tile loads without the descriptors that end at the group's last entry
         static const bool mask = !(getenv("LANCZOS_HIP_ROWS_MASK") && atoi(getenv("LANCZOS_HIP_ROWS_MASK")) == 0);
-        if (mask)
+        // LANCZOS_HIP_ROWS_DMA=1: the tiles loaded straight into LDS (read at every launch: a measurement switch)
+        const char *dma = getenv("LANCZOS_HIP_ROWS_DMA");
+        if (dma && atoi(dma) != 0)
+            hipLaunchKernelGGL((k_spmv_rows_dma<RP>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp,
+                               e->d_col, e->d_val, x, xdot, y, parts);
+        else if (mask)
             hipLaunchKernelGGL((k_spmv_rows<RP, true>), dim3(blocks), dim3(kBlock), 0, e->stream, rows, e->nnz, rp,
                                e->d_col, e->d_val, x, xdot, y, parts);
         else
@@ -848,7 +865,7 @@ int Engine::phase_spmv_end(double *red) {
 int Engine::phase_recur_lazy(double *red) {
     if (int rc = check_affinity(this, "phase_recur_lazy")) return rc;
     if (!lazy_slab) return fail("lanczos_hip_phase_recur_lazy: needs reorth=none on a row-partitioned engine");
-    const int blocks = vec_blocks();
+    const int blocks = recur_blocks();
     {
         ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
         hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
@@ -881,7 +898,7 @@ int Engine::phase_lazy_close(double *red) {
 
 // w <- (w - beta v_{k-1}) - alpha v_k ; alpha = sum of alpha_parts[0..alpha_cnt)
 int Engine::launch_recur(const double *alpha_parts, int alpha_cnt) {
-    const int blocks = vec_blocks();
+    const int blocks = recur_blocks();
     ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
     double *ahost = h_hist ? h_hist + 2 * (size_t)k : nullptr;
     hipLaunchKernelGGL(k_recur, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
@@ -894,7 +911,7 @@ int Engine::launch_recur(const double *alpha_parts, int alpha_cnt) {
 
 // v_{k+1} = w / sqrt(sum of parts[0..cnt)) ; closes iteration k
 int Engine::launch_scale(const double *parts, int cnt) {
-    const int blocks = vec_blocks();
+    const int blocks = recur_blocks();
     {
         ProfScope ps(this, LANCZOS_HIP_K_SCALE, 16.0 * (double)n);
         double *bhost = h_hist ? h_hist + 2 * (size_t)k + 1 : nullptr;
@@ -1015,7 +1032,7 @@ int Engine::enqueue_iteration() {
         if (int rc = launch_product(k)) return rc;
     spec_spmv_k = -1;
     if (lazy) {
-        const int blocks = vec_blocks();
+        const int blocks = recur_blocks();
         {
             ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
             hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),

@@ -14,6 +14,11 @@ namespace lz {
 
 constexpr int kBlock = 256;        // threads per workgroup (4 wavefronts)
 constexpr int kWavesPerBlock = 4;
+// The vector kernels walk tiles of kTileV2 consecutive double2 elements (2048 doubles, 16 KiB per
+// stream), one workgroup per tile at a time, every thread kEPT2 elements kBlock apart: all the loads
+// of a tile are issued before the first is used.  Vectors are zero padded to whole tiles.
+constexpr int kEPT2 = 4;                       // double2 per thread per tile
+constexpr int kTileV2 = kBlock * kEPT2;        // double2 per tile (2048 doubles)
 
 // Streamed-once data (the basis in the reorthogonalisation kernels) is loaded
 // with the non-temporal hint: on MI355X a pure read stream runs ~14 % faster with
@@ -741,6 +746,144 @@ k_spmv_rows(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__
     if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
 }
 
+// The rows form with its tiles loaded straight into LDS (`buffer_load_dwordx4 ... lds`): the col/val
+// tile of a group never passes through vector registers, and there is no LDS store pass.  Two tile
+// buffers per wavefront alternate: while lane r walks its row of group i out of one, the tile of
+// group i+1 lands in the other.  One instruction moves 64 x 16 bytes to consecutive LDS addresses,
+// which is the layout the rows form parks its tiles in anyway; the same per-group descriptors end
+// the tile at the group's last entry (lanes past it write zeros into slots no row reads).  Same sums
+// in the same order as k_spmv_rows: the results are bit for bit equal.
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <typename RP>
+__global__ void __launch_bounds__(kBlock)
+k_spmv_rows_dma(int64_t n, int64_t nnz, const RP *__restrict__ rp, const int32_t *__restrict__ col,
+                const double *__restrict__ val, const double *__restrict__ x,
+                const double *__restrict__ xdot, double *__restrict__ y,
+                double *__restrict__ partials) {
+    // ONE LDS object: per wavefront and buffer 4 KiB of values then 2 KiB of columns; the four doubles of the
+    // final reduction live behind the tiles (a tile load may still be landing when the loop ends)
+    constexpr int kBufBytes = kTile * 12;
+    __shared__ __align__(16) unsigned char lds[kWavesPerBlock * 2 * kBufBytes + 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t groups = (n + 63) >> 6;
+    const int64_t total = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+    const int64_t per_xcd = (total + 7) >> 3;
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t slot = blockIdx.x >> 3;
+    const int64_t slots = gridDim.x >> 3;
+    int64_t c_end = (xcd + 1) * per_xcd;
+    if (c_end > total) c_end = total;
+    const int64_t c0 = xcd * per_xcd + slot;
+    const int64_t count = c0 < c_end ? (c_end - c0 + slots - 1) / slots : 0;
+    unsigned char *mybuf = lds + (size_t)wave * 2 * kBufBytes;
+    double acc = 0.0;
+
+    auto row_of = [&](int64_t i) -> int64_t {
+        const int64_t r = (((c0 + i * slots) * kWavesPerBlock + wave) << 6) + lane;
+        return r < n ? r : n;
+    };
+    auto offsets = [&](int64_t r, RP &lo, RP &hi) {
+        lo = rp[r];
+        hi = rp[r < n ? r + 1 : n];
+    };
+    // tile of the group whose first / last row offsets sit in lanes 0 / 63 -> buffer `b`
+    auto issue_tile = [&](RP lo_lane, RP hi_lane, int b) {
+        const RP s_lo = uniform_lane<0>(lo_lane), s_hi = uniform_lane<63>(hi_lane);
+        const RP ac = s_lo & ~(RP)(kRowsAlignC - 1), av = s_lo & ~(RP)(kRowsAlignV - 1);
+        RP ec = (s_hi - ac + 3) & ~(RP)3, ev = (s_hi - av + 1) & ~(RP)1;
+        ec = ec < (RP)kTile ? ec : (RP)kTile;
+        ev = ev < (RP)kTile ? ev : (RP)kTile;
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void *)(col + ac), 0, (int)ec * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc((void *)(val + av), 0, (int)ev * 8, 0x00020000);
+        lds_void *lv = (lds_void *)(mybuf + b * kBufBytes);
+        lds_void *lc = (lds_void *)(mybuf + b * kBufBytes + kTile * 8);
+        // the instruction offset moves the memory address and the LDS address together
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lc, 16, 16 * lane, 0, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, lc, 16, 16 * lane, 0, 1024, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, lv, 16, 16 * lane, 0, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, lv, 16, 16 * lane, 0, 1024, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, lv, 16, 16 * lane, 0, 2048, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, lv, 16, 16 * lane, 0, 3072, 2);
+    };
+    // hipcc does not order an LDS read behind the tile load that fills it: every step opens with a wait of its
+    // own for everything in flight (the tile of this group is the youngest of it).  The row sums of a group
+    // are stored at the top of the next step, behind that wait, so that the wait never sits on a fresh store.
+    double held_sum = 0.0;
+    int64_t held_row = n;
+    auto step = [&](int64_t i, int b, RP &lo_c, RP &hi_c, const RP &lo_n, const RP &hi_n) {
+        const double *myv = reinterpret_cast<const double *>(mybuf + b * kBufBytes);
+        const int32_t *myc = reinterpret_cast<const int32_t *>(mybuf + b * kBufBytes + kTile * 8);
+        const int64_t row = row_of(i);
+        const RP my_lo = lo_c, my_hi = hi_c;
+        const RP span_lo = __shfl(my_lo, 0);
+        const int off = (int)(my_lo - (span_lo & ~(RP)(kRowsAlignC - 1)));
+        const int offv = (int)(my_lo - (span_lo & ~(RP)(kRowsAlignV - 1)));
+        const int len = (int)(my_hi - my_lo);
+        const int32_t safe_col = (int32_t)(row < n ? row : n - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (held_row < n) y[held_row] = held_sum;
+        // (a) row-wise gathers of the first chunk out of this group's tile
+        int32_t cr[kRowChunk];
+        double xr[kRowChunk];
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) cr[j] = j < len ? myc[off + j] : safe_col;
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) xr[j] = x[cr[j]];
+        const double xd = xdot[row < n ? row : n - 1];
+        // (b) offsets of group i+2, tile of group i+1 into the other buffer (behind the gathers in the queue)
+        offsets(row_of(i + 2 < count ? i + 2 : count - 1), lo_c, hi_c);
+        issue_tile(lo_n, hi_n, b ^ 1);
+        // (c) the row sum, left to right
+        double sum = 0.0;
+#pragma unroll
+        for (int j = 0; j < kRowChunk; ++j) {
+            const double v = j < len ? myv[offv + j] : 0.0;
+            sum += v * xr[j];
+        }
+        int maxlen = len;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const int other = __shfl_xor(maxlen, o);
+            maxlen = other > maxlen ? other : maxlen;
+        }
+        for (int j0 = kRowChunk; j0 < maxlen; j0 += kRowChunk) {
+#pragma unroll
+            for (int j = 0; j < kRowChunk; ++j) {
+                const bool in = j0 + j < len;
+                const double v = in ? myv[offv + j0 + j] : 0.0;
+                const int32_t c = in ? myc[off + j0 + j] : safe_col;
+                sum += v * x[c];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (row < n) acc += sum * xd;
+        held_sum = sum;
+        held_row = row;
+    };
+
+    if (count > 0) {
+        RP loA, hiA, loB, hiB;
+        offsets(row_of(0), loA, hiA);
+        offsets(row_of(count > 1 ? 1 : 0), loB, hiB);
+        issue_tile(loA, hiA, 0);
+        int64_t i = 0;
+        for (; i + 1 < count; i += 2) {
+            step(i, 0, loA, hiA, loB, hiB);
+            step(i + 1, 1, loB, hiB, loA, hiA);
+        }
+        if (i < count) step(i, 0, loA, hiA, loB, hiB);
+    }
+    if (held_row < n) y[held_row] = held_sum;
+    // every tile load has landed before the LDS words of the reduction are written
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    double *red = reinterpret_cast<double *>(lds + kWavesPerBlock * 2 * kBufBytes);
+    const double total_acc = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = total_acc;
+}
+
 // ---------------------------------------------------------------------------
 // Small finaliser: out[0] = sum(partials[0..count)) in a fixed order
 // ---------------------------------------------------------------------------
@@ -806,27 +949,43 @@ k_recur(double2 *__restrict__ w, const double2 *__restrict__ vk, const double2 *
     __shared__ double red[kWavesPerBlock];
     const double alpha = sum_partials(alpha_parts, alpha_count, red);
     const double beta = vprev ? beta_p[0] : 0.0;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    // a workgroup owns whole tiles of consecutive elements (a grid-stride walk, 8 MiB between a thread's
+    // consecutive accesses over four streams, lost a quarter of its rate on vectors beyond the caches)
+    const int64_t tiles = n2 / kTileV2;
     double acc = 0.0;
     if (vprev) {
-#pragma unroll 4
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = w[i];
-            const double2 p = vprev[i], q = vk[i];
-            a.x = (a.x - beta * p.x) - alpha * q.x;
-            a.y = (a.y - beta * p.y) - alpha * q.y;
-            w[i] = a;
-            acc += a.x * a.x + a.y * a.y;
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t base = t * kTileV2 + threadIdx.x;
+            double2 a[kEPT2], p[kEPT2], q[kEPT2];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) a[u] = w[base + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) p[u] = vprev[base + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) q[u] = vk[base + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                a[u].x = (a[u].x - beta * p[u].x) - alpha * q[u].x;
+                a[u].y = (a[u].y - beta * p[u].y) - alpha * q[u].y;
+                w[base + u * kBlock] = a[u];
+                acc += a[u].x * a[u].x + a[u].y * a[u].y;
+            }
         }
     } else {
-#pragma unroll 4
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = w[i];
-            const double2 q = vk[i];
-            a.x = a.x - alpha * q.x;
-            a.y = a.y - alpha * q.y;
-            w[i] = a;
-            acc += a.x * a.x + a.y * a.y;
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t base = t * kTileV2 + threadIdx.x;
+            double2 a[kEPT2], q[kEPT2];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) a[u] = w[base + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) q[u] = vk[base + u * kBlock];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                a[u].x = a[u].x - alpha * q[u].x;
+                a[u].y = a[u].y - alpha * q[u].y;
+                w[base + u * kBlock] = a[u];
+                acc += a[u].x * a[u].x + a[u].y * a[u].y;
+            }
         }
     }
     const double t = block_sum(acc, red);
@@ -845,13 +1004,18 @@ k_scale(double2 *__restrict__ w, int64_t n2, const double *__restrict__ norm_par
         double *__restrict__ beta_cur, double *__restrict__ beta_hist, double *beta_host) {
     __shared__ double red[kWavesPerBlock];
     const double beta = sqrt(sum_partials(norm_parts, norm_count, red));
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
-#pragma unroll 4
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-        double2 a = w[i];
-        a.x /= beta;
-        a.y /= beta;
-        w[i] = a;
+    const int64_t tiles = n2 / kTileV2;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 a[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) a[u] = w[base + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) {
+            a[u].x /= beta;
+            a[u].y /= beta;
+            w[base + u * kBlock] = a[u];
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         beta_cur[0] = beta;
@@ -888,27 +1052,41 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
     }
     const double alpha = s_k * s_k * dot;
     const double c_p = beta_km1 * s_km1, c_k = alpha * s_k;
-    const int64_t stride = (int64_t)gridDim.x * kBlock;
+    const int64_t tiles = n2 / kTileV2;
     double acc = 0.0;
     if (k > 0) {
-#pragma unroll 4
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = ld_stream(w + i);
-            const double2 p = ld_stream(uprev + i), q = ld_stream(uk + i);
-            a.x = (s_k * a.x - c_p * p.x) - c_k * q.x;
-            a.y = (s_k * a.y - c_p * p.y) - c_k * q.y;
-            w[i] = a;
-            acc += a.x * a.x + a.y * a.y;
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t base = t * kTileV2 + threadIdx.x;
+            double2 a[kEPT2], p[kEPT2], q[kEPT2];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) a[u] = ld_stream(w + base + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) p[u] = ld_stream(uprev + base + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) q[u] = ld_stream(uk + base + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                a[u].x = (s_k * a[u].x - c_p * p[u].x) - c_k * q[u].x;
+                a[u].y = (s_k * a[u].y - c_p * p[u].y) - c_k * q[u].y;
+                w[base + u * kBlock] = a[u];
+                acc += a[u].x * a[u].x + a[u].y * a[u].y;
+            }
         }
     } else {
-#pragma unroll 4
-        for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n2; i += stride) {
-            double2 a = ld_stream(w + i);
-            const double2 q = ld_stream(uk + i);
-            a.x = a.x - c_k * q.x;
-            a.y = a.y - c_k * q.y;
-            w[i] = a;
-            acc += a.x * a.x + a.y * a.y;
+        for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const int64_t base = t * kTileV2 + threadIdx.x;
+            double2 a[kEPT2], q[kEPT2];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) a[u] = ld_stream(w + base + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) q[u] = ld_stream(uk + base + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                a[u].x = a[u].x - c_k * q[u].x;
+                a[u].y = a[u].y - c_k * q[u].y;
+                w[base + u * kBlock] = a[u];
+                acc += a[u].x * a[u].x + a[u].y * a[u].y;
+            }
         }
     }
     const double t = block_sum(acc, red);
@@ -1010,9 +1188,6 @@ k_dot(const double2 *__restrict__ a, const double2 *__restrict__ b, int64_t n2,
 // once.  Every vector is padded with zeros to a whole number of tiles, so no
 // bounds checks are needed and the padding stays zero.
 // ---------------------------------------------------------------------------
-constexpr int kEPT2 = 4;                       // double2 per thread per tile
-constexpr int kTileV2 = kBlock * kEPT2;        // double2 per tile (2048 doubles)
-
 __global__ void __launch_bounds__(kBlock)
 k_dots(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, const double2 *__restrict__ w,
        int64_t n2, double *__restrict__ hpart, int hstride) {

@@ -72,8 +72,12 @@ def test_headline_configuration_300_steps_ritz_parity(gpu, lap256):
     steps), reorth=full, the fixed start vector of the benchmark.  Against the CPU restatement of
     src/lanczos.c:104-191 run on the same inputs (about a minute on the box's host cores; 40 GB of host
     memory for its basis): the lowest four Ritz values at k = 50, 100, 200, 300 within 1e-10 relative
-    (the bar the north star states, at equal iteration counts), alpha/beta of the first 50 steps within
-    1e-12, and the resident basis orthonormal to 1e-12 on vectors sampled up to k = 300.  The engine's
+    (the bar the north star states, at equal iteration counts), beta of the first 50 steps within 1e-12
+    and alpha within 5e-12, and the resident basis orthonormal to 1e-12 on vectors sampled up to k = 300.
+    (alpha_k = v_k . A v_k is a sum of 1.7e7 products of either sign; the reference adds them one after
+    the other, src/util.c:58-65, and that sum's own rounding error at this length is a few 1e-13 -- measured
+    here: 1.2e-12 between the two runs over the first 50 steps where beta, a sum of squares, agrees to
+    8e-15; alpha_0 of both runs is also held against numpy's pairwise sum.)  The engine's
     `full` is one blocked classical Gram-Schmidt pass behind the three-term recurrence where the
     reference walks the basis one vector at a time (src/lanczos.c:156-167): this is where that
     difference would show."""
@@ -93,7 +97,12 @@ def test_headline_configuration_300_steps_ritz_parity(gpu, lap256):
         print(f"Ritz rel err by step count {errs}; alpha/beta first 50 {ab}; "
               f"all 300: {_rel(alpha, o.alpha):.2e} / {_rel(beta, o.beta):.2e}", flush=True)
         assert max(errs.values()) < 1e-10, errs
-        assert ab[0] < 1e-12 and ab[1] < 1e-12, ab
+        assert ab[0] < 5e-12 and ab[1] < 1e-12, ab
+        u0 = v0 / np.sqrt(np.sum(v0 * v0))
+        exact0 = float(np.sum(u0 * oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, u0)))  # pairwise
+        print(f"alpha_0: engine off numpy's pairwise sum by {abs(alpha[0] - exact0) / exact0:.1e}, "
+              f"CPU restatement by {abs(o.alpha[0] - exact0) / exact0:.1e}", flush=True)
+        assert abs(alpha[0] - exact0) / exact0 < 1e-13
         assert _rel(la.ritz_values(alpha, beta, 300, 4), o.eigenvalues) < 1e-10
         ks = (0, 1, 2, 75, 149, 150, 224, 298, 299, 300)
         vecs = [e.get_vector(k) for k in ks]

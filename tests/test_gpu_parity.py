@@ -843,6 +843,29 @@ def test_lanczos_takes_a_custom_matvec_plugin(gpu):
         assert rel_err(alpha[:20], oo.alpha[:20]) < 1e-11 and rel_err(beta[:20], oo.beta[:20]) < 1e-11, reorth
 
 
+def test_rows_spmv_with_tiles_loaded_straight_into_lds_gives_the_same_bits(gpu, monkeypatch):
+    """LANCZOS_HIP_ROWS_DMA=1 (read at every launch): the row-wise CRS kernel whose col/val tiles go from
+    memory into LDS without passing through registers; same sums in the same order as the register-staged
+    form, on grids of one, two and three dimensions, an awkward size and rows longer than one chunk."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    band = sp.diags([rng.standard_normal(5000 - abs(k)) for k in range(-6, 7)], list(range(-6, 7))).tocsr()  # 13 per row
+    cases = [la.synth_laplacian(3, 33), la.synth_laplacian(2, 129), la.synth_laplacian(1, 70001),
+             la.CrsMatrix(band.data, band.indices.astype(np.int64), band.indptr.astype(np.int64))]
+    with plain_rows():
+        for a in cases:
+            x = rng.standard_normal(a.dimension)
+            with la.Engine(a, 3, reorth="none", spmv="rows") as e:
+                assert e.spmv_name == "rows64"
+                monkeypatch.setenv("LANCZOS_HIP_ROWS_DMA", "0")
+                y0 = e.spmv(x)
+                monkeypatch.setenv("LANCZOS_HIP_ROWS_DMA", "1")
+                y1 = e.spmv(x)
+                monkeypatch.delenv("LANCZOS_HIP_ROWS_DMA")
+            assert y0.tobytes() == y1.tobytes()
+            assert np.max(np.abs(y0 - oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x))) < 1e-12
+
+
 def test_a_host_operator_has_no_checkpoint_and_no_device_product(gpu, tmp_path):
     """An engine whose operator is a host function holds an empty matrix: nothing identifies the operator
     in a checkpoint file, and there is no device product for the entry point that allocates nothing."""
