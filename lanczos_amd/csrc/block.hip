@@ -22,6 +22,7 @@
 
 #include "block_kernels.hip.h"
 #include "engine.h"
+#include "spmm_hub.h"
 
 #define HIP_TRY(call)                                                                             \
     do {                                                                                          \
@@ -50,7 +51,11 @@ struct BlockEngine {
     double *d_TA = nullptr, *d_TB = nullptr;
     int *d_status = nullptr;
     int *d_med_rows = nullptr, *d_long_rows = nullptr;  // rows over kMedRow / over kLongRow entries
+    long long *d_xcd_split = nullptr;                   // [9] row octets of the eight XCDs' ranges (k_spmm16)
     int n_med = 0, n_long = 0;
+    int med_row = kMedRow;      // rows of more entries leave k_spmm16
+    HubStream hub;              // those rows' entries regrouped by column class (power-law graphs); empty: row-wise kernels
+    int64_t hot_degree_floor = 0;
     bool profile = false;
     double prof_ms[LANCZOS_HIP_BK_COUNT] = {0};
     double prof_bytes[LANCZOS_HIP_BK_COUNT] = {0};
@@ -76,6 +81,8 @@ struct BlockEngine {
         (void)hipFree(d_status);
         (void)hipFree(d_long_rows);
         (void)hipFree(d_med_rows);
+        (void)hipFree(d_xcd_split);
+        hub_free(&hub);
         delete base;
     }
 
@@ -130,19 +137,50 @@ struct BlockEngine {
         HIP_TRY(hipMalloc(&d_TB, sizeof(double) * 256 * (size_t)max_steps));
         HIP_TRY(hipMalloc(&d_status, sizeof(int) * 4));
         HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int) * 4, stream()));
-        // rows too long for eight lanes get a wavefront or a workgroup each; at most nnz / threshold
-        // rows can qualify
-        const int med_cap = (int)std::min<int64_t>(n, base->nnz / kMedRow + 1);
+        // rows too long for eight lanes get a wavefront or a workgroup each
+        if (int rc = find_long_rows()) return rc;
+        HIP_TRY(hipMalloc(&d_xcd_split, sizeof(long long) * 9));
+        // Rows of more than kMedRow entries holding a good part of the matrix (a power-law graph): their entries are
+        // regrouped by column class so that the eight L2s cache disjoint parts of X (spmm_hub.hip).  A handful of
+        // long rows in an otherwise regular matrix keep the row-wise kernels, and so does LANCZOS_HIP_SPMM_HUB=0.
+        const char *hub_env = getenv("LANCZOS_HIP_SPMM_HUB");
+        const bool hub_off = hub_env && atoi(hub_env) == 0, hub_forced = hub_env && atoi(hub_env) == 2;
+        if (!hub_off && n_med + n_long > 0 && (hub_forced || (int64_t)(n_med + n_long) * 64 > n / 16)) {
+            // the regrouped stream takes every row of more than kHubRow entries (LANCZOS_HIP_SPMM_HUB_ROW: 4..64)
+            int keep = kHubRow;
+            if (const char *s = getenv("LANCZOS_HIP_SPMM_HUB_ROW"))
+                if (atoi(s) >= 4 && atoi(s) <= 64) keep = atoi(s);
+            med_row = keep;
+            if (int rc = find_long_rows()) return rc;
+            if (int rc = hub_build(base, d_med_rows, n_med, d_long_rows, n_long, hot_degree_floor, &hub)) return rc;
+            if (!hub.ready()) {  // no memory for it: back to the row-wise kernels and their threshold
+                med_row = kMedRow;
+                if (int rc = find_long_rows()) return rc;
+            }
+        }
+        return row_cost_split(base, med_row, 8, n_pad / 8, d_xcd_split);
+    }
+
+    // d_med_rows / d_long_rows: the rows of more than med_row / kLongRow entries
+    int find_long_rows() {
+        (void)hipFree(d_med_rows);
+        (void)hipFree(d_long_rows);
+        d_med_rows = d_long_rows = nullptr;
+        // at most nnz / threshold rows can qualify
+        const int med_cap = (int)std::min<int64_t>(n, base->nnz / med_row + 1);
         const int lng_cap = (int)std::min<int64_t>(n, base->nnz / kLongRow + 1);
         HIP_TRY(hipMalloc(&d_med_rows, sizeof(int) * (size_t)med_cap));
         HIP_TRY(hipMalloc(&d_long_rows, sizeof(int) * (size_t)lng_cap));
+        HIP_TRY(hipMemsetAsync(d_status + 1, 0, sizeof(int) * 2, stream()));
         const int fb = (int)std::min<int64_t>(groups_spmm, (n + kThreads - 1) / kThreads);
         if (base->rp64)
             hipLaunchKernelGGL((k_find_long_rows<int64_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
-                               (const int64_t *)base->d_rp, d_med_rows, med_cap, d_long_rows, lng_cap, d_status + 1);
+                               (const int64_t *)base->d_rp, med_row, d_med_rows, med_cap, d_long_rows, lng_cap,
+                               d_status + 1);
         else
             hipLaunchKernelGGL((k_find_long_rows<int32_t>), dim3(fb), dim3(kThreads), 0, stream(), n,
-                               (const int32_t *)base->d_rp, d_med_rows, med_cap, d_long_rows, lng_cap, d_status + 1);
+                               (const int32_t *)base->d_rp, med_row, d_med_rows, med_cap, d_long_rows, lng_cap,
+                               d_status + 1);
         HIP_TRY(hipGetLastError());
         int counts[2] = {0, 0};
         HIP_TRY(hipMemcpyAsync(counts, d_status + 1, sizeof(counts), hipMemcpyDeviceToHost, stream()));
@@ -163,10 +201,14 @@ struct BlockEngine {
         Scope ps(this, LANCZOS_HIP_BK_SPMM, spmm_bytes());
         if (base->rp64)
             hipLaunchKernelGGL((k_spmm16<int64_t>), dim3(groups_spmm), dim3(kThreads), 0, stream(), n, n_pad,
-                               (const int64_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+                               (const int64_t *)base->d_rp, base->d_col, base->d_val, X, Y, (const long long *)d_xcd_split, med_row);
         else
             hipLaunchKernelGGL((k_spmm16<int32_t>), dim3(groups_spmm), dim3(kThreads), 0, stream(), n, n_pad,
-                               (const int32_t *)base->d_rp, base->d_col, base->d_val, X, Y);
+                               (const int32_t *)base->d_rp, base->d_col, base->d_val, X, Y, (const long long *)d_xcd_split, med_row);
+        if (hub.ready()) {
+            if (int rc = hub_spmm(hub, stream(), base->cus, X, Y)) return rc;
+            return 0;
+        }
         if (n_med > 0) {
             const int mb = (n_med + 3) / 4;
             if (base->rp64)
@@ -334,6 +376,25 @@ int lanczos_hip_block_create(lanczos_hip_block **out, int64_t n, int64_t nnz, co
     if (int rc = lz::Engine::create(&base, n, nnz, row_head_indexes, column_index, values, 2, &opt)) return rc;
     BlockEngine *b = new BlockEngine();
     b->base = base;
+    {
+        // the columns meant to stay in the L2s while the hub rows are multiplied: the most popular ones, about
+        // three quarters of the eight L2s' lines (LANCZOS_HIP_SPMM_HOT_COLUMNS; 0: no such split).  A column's
+        // popularity is taken to be its row's length (the matrix is symmetric).
+        int64_t hot_columns = 0;
+        if (const char *s = getenv("LANCZOS_HIP_SPMM_HOT_COLUMNS")) hot_columns = atoll(s);
+        b->hot_degree_floor = 0;
+        if (hot_columns > 0) {
+            constexpr int64_t cap = 1 << 20;
+            std::vector<int64_t> hist((size_t)cap + 1, 0);
+            for (int64_t i = 0; i < n; ++i) hist[(size_t)std::min(row_head_indexes[i + 1] - row_head_indexes[i], cap)] += 1;
+            int64_t acc = 0, floor_deg = cap + 1;
+            for (int64_t d = cap; d >= 1 && acc + hist[(size_t)d] <= hot_columns; --d) {
+                acc += hist[(size_t)d];
+                floor_deg = d;
+            }
+            b->hot_degree_floor = floor_deg;
+        }
+    }
     if (int rc = b->alloc(max_steps, want_profile != 0)) {
         delete b;
         return rc;

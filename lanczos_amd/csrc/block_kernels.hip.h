@@ -36,59 +36,71 @@ __device__ __forceinline__ double ld_nt(const double *p) { return __builtin_nont
 // the group loads 8 (col, val) pairs at a time with one coalesced load each and
 // hands them round with ds_bpermute, so every gather reads one full 128-byte
 // row of X.  Row sums run left to right in entry order.  Rows n..n_pad-1 are
-// written as zeros.  Workgroup b serves the b % 8-th eighth of the rows
+// written as zeros.  Workgroup b serves the b % 8-th of eight contiguous row ranges
 // (workgroups b and b + 8 share an XCD and its L2).
 // ---------------------------------------------------------------------------
 typedef double d2v __attribute__((ext_vector_type(2)));
 
 constexpr int kMedRow = 64;     // rows with more entries leave the main kernel: one wavefront each (k_spmm16_medium)
 constexpr int kLongRow = 4096;  // ... and above this one workgroup each (k_spmm16_long)
+// (on power-law graphs the main kernel keeps rows of up to kHubRow entries only and the rest goes through the
+// regrouped stream of spmm_hub.hip: eight lanes walking a row of 40 entries take five dependent rounds of
+// loads while the seven other rows of their wavefront wait)
+constexpr int kHubRow = 16;
 
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
 k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__restrict__ col,
-         const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y) {
+         const double *__restrict__ val, const double *__restrict__ X, double *__restrict__ Y,
+         const long long *__restrict__ xcd_split, int med_row) {
     // eight lanes own one row, lane c its columns 2c and 2c + 1; a wavefront works on 8 rows at once
     const int lane = threadIdx.x & 63, c = lane & 7, g = lane >> 3, wave = threadIdx.x >> 6;
-    const int64_t octs = n_pad / 8;
+    // this XCD's range of row octets (ranges of equal cost: equal row counts leave seven XCDs waiting for the one
+    // that got the heavy rows of a power-law graph)
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, per = gridDim.x >> 3;
-    const int64_t q_lo = octs * xcd / 8, q_hi = octs * (xcd + 1) / 8;
+    const int64_t q_lo = xcd_split[xcd], q_hi = xcd_split[xcd + 1];
     const int64_t step = (int64_t)per * 4;
     int64_t q = q_lo + (int64_t)slot * 4 + wave;
-    // the offsets, and the first eight entries of each row, are fetched one round ahead
-    int64_t e0 = 0;
-    int len = 0, mycol = 0;
-    double myval = 0.0;
-    auto fetch = [&](int64_t qq) {
-        e0 = 0;
-        len = 0;
-        mycol = 0;
-        myval = 0.0;
+    // Three rounds are in flight per wavefront: the row offsets of round i + 2 and the first eight entries of
+    // each row of round i + 1 are requested before the gathers of round i, so no round waits for an offset
+    // before it can ask for its entries (queue order: offsets, entries, gathers; the gathers' wait covers all).
+    auto fetch_offsets = [&](int64_t qq, int64_t &e0o, int &leno) {
+        e0o = 0;
+        leno = 0;
         const int64_t r = qq * 8 + g;
         if (qq < q_hi && r < n) {
-            e0 = (int64_t)rp[r];
-            const int64_t full = (int64_t)rp[r + 1] - e0;
-            len = full > kMedRow ? -1 : (int)full;  // -1: left to k_spmm16_medium / k_spmm16_long
-            if (c < len) {
-                mycol = __builtin_nontemporal_load(col + e0 + c);
-                myval = __builtin_nontemporal_load(val + e0 + c);
-            }
+            e0o = (int64_t)rp[r];
+            const int64_t full = (int64_t)rp[r + 1] - e0o;
+            leno = full > med_row ? -1 : (int)full;  // -1: left to the kernels for long rows
         }
     };
-    fetch(q);
+    auto fetch_entries = [&](int64_t e0i, int leni, int &colo, double &valo) {
+        colo = 0;
+        valo = 0.0;
+        if (c < leni) {
+            colo = __builtin_nontemporal_load(col + e0i + c);
+            valo = __builtin_nontemporal_load(val + e0i + c);
+        }
+    };
+    int64_t e0 = 0, e0_n = 0, e0_nn = 0;
+    int len = 0, len_n = 0, len_nn = 0, mycol = 0, mycol_n = 0;
+    double myval = 0.0, myval_n = 0.0;
+    fetch_offsets(q, e0, len);
+    fetch_entries(e0, len, mycol, myval);
+    fetch_offsets(q + step, e0_n, len_n);
     for (; q < q_hi; q += step) {
         const int64_t r = q * 8 + g;
         const int64_t ce0 = e0;
         const int clen = len;
         int ccol = mycol;
         double cval = myval;
-        fetch(q + step);
-        int maxlen = clen;
-        maxlen = max(maxlen, __shfl_xor(maxlen, 8));
-        maxlen = max(maxlen, __shfl_xor(maxlen, 16));
-        maxlen = max(maxlen, __shfl_xor(maxlen, 32));
+        fetch_offsets(q + 2 * step, e0_nn, len_nn);
+        fetch_entries(e0_n, len_n, mycol_n, myval_n);
+        // Each group of eight lanes walks its own row: a group whose row has ended issues no gathers while its
+        // neighbours go on (padding every row to the longest of the wavefront's eight cost five L1 accesses per
+        // useful one on a power-law graph, where an octet of rows often holds one of 40 entries and seven of 2).
         d2v acc = d2v{0.0, 0.0};
-        for (int p = 0; p < maxlen; p += 8) {
+        for (int p = 0; p < clen; p += 8) {
             if (p > 0) {
                 ccol = 0;
                 cval = 0.0;
@@ -97,33 +109,44 @@ k_spmm16(int64_t n, int64_t n_pad, const RP *__restrict__ rp, const int32_t *__r
                     cval = val[ce0 + p + c];
                 }
             }
-            const int cnt = min(8, maxlen - p);  // wave-uniform; entries past a row's end are (col 0, val 0)
-#pragma unroll 8
-            for (int j = 0; j < cnt; ++j) {
+            const int cnt = min(8, clen - p);  // the same for the eight lanes of a group
+            d2v x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
                 const int cj = __shfl(ccol, j, 8);
-                const double vj = __shfl(cval, j, 8);
-                const d2v x = *reinterpret_cast<const d2v *>(X + (int64_t)cj * kW + 2 * c);
-                acc.x += vj * x.x;
-                acc.y += vj * x.y;
+                x[j] = d2v{0.0, 0.0};
+                if (j < cnt) x[j] = *reinterpret_cast<const d2v *>(X + (int64_t)cj * kW + 2 * c);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const double vj = __shfl(cval, j, 8);  // 0 past the row's end
+                acc.x += vj * x[j].x;
+                acc.y += vj * x[j].y;
             }
         }
         if (clen >= 0) __builtin_nontemporal_store(acc, reinterpret_cast<d2v *>(Y + r * kW + 2 * c));
+        e0 = e0_n;
+        len = len_n;
+        mycol = mycol_n;
+        myval = myval_n;
+        e0_n = e0_nn;
+        len_n = len_nn;
     }
 }
 
-// med[0 .. count[0]) = the rows with kMedRow < entries <= kLongRow, lng[0 .. count[1]) those with more
+// med[0 .. count[0]) = the rows with med_row < entries <= kLongRow, lng[0 .. count[1]) those with more
 // (any order)
 template <typename RP>
 __global__ void __launch_bounds__(kThreads)
-k_find_long_rows(int64_t n, const RP *__restrict__ rp, int *__restrict__ med, int med_cap, int *__restrict__ lng,
-                 int lng_cap, int *__restrict__ count) {
+k_find_long_rows(int64_t n, const RP *__restrict__ rp, int med_row, int *__restrict__ med, int med_cap,
+                 int *__restrict__ lng, int lng_cap, int *__restrict__ count) {
     const int64_t stride = (int64_t)gridDim.x * kThreads;
     for (int64_t r = (int64_t)blockIdx.x * kThreads + threadIdx.x; r < n; r += stride) {
         const int64_t len = (int64_t)rp[r + 1] - (int64_t)rp[r];
         if (len > kLongRow) {
             const int at = atomicAdd(count + 1, 1);
             if (at < lng_cap) lng[at] = (int)r;
-        } else if (len > kMedRow) {
+        } else if (len > med_row) {
             const int at = atomicAdd(count, 1);
             if (at < med_cap) med[at] = (int)r;
         }

@@ -54,6 +54,42 @@ def test_spmm_with_empty_and_very_long_rows(gpu):
     assert np.all(y[np.diff(a.row_head_indexes) == 0] == 0)
 
 
+@pytest.mark.parametrize("hot_columns", ["196608", "0", "300"])
+def test_spmm_of_hub_rows_regrouped_by_column_class(gpu, monkeypatch, hot_columns):
+    """Power-law graphs: the rows of more than 16 entries hold nearly all of the matrix; their entries are regrouped
+    by a hash of the column (so that each XCD's L2 caches its own eighth of X) and by column popularity.
+    Against the numpy product, against the row-wise kernels (LANCZOS_HIP_SPMM_HUB=0), twice for the same bits;
+    with every column in the popular set (the default at this size), with no such split, and with 300 popular
+    columns (both kinds of classes in use).  The ragged matrix adds unsorted duplicate columns, empty rows and
+    rows of 513 to 40000 entries, some of which cross dozens of 64-entry slices."""
+    from matrices import rmat_laplacian
+    from test_gpu_parity import crs_from_scipy, irregular_matrix
+    monkeypatch.setenv("LANCZOS_HIP_SPMM_HOT_COLUMNS", hot_columns)
+    cases = [crs_from_scipy(rmat_laplacian(15)), crs_from_scipy(rmat_laplacian(12, edge_factor=40)),
+             irregular_matrix(50000, 4, long_rows=((7, 600), (31000, 5000), (49999, 40000), (0, 513), (123, 17),
+                                                   (124, 16), (125, 257)))]
+    for a in cases:
+        x = start_block(a.dimension, 12)
+        want = bl.spmm(a.row_head_indexes, a.column_index, a.values, x)
+        bound = bl.spmm(a.row_head_indexes, a.column_index, np.abs(a.values), np.abs(x))
+        maxlen = int(np.diff(a.row_head_indexes).max())
+        got = {}
+        for mode in ("2", "0"):                      # 2: regrouped form whatever the share of such rows; 0: row-wise
+            monkeypatch.setenv("LANCZOS_HIP_SPMM_HUB", mode)
+            with la.BlockEngine(a, 2) as e:
+                e.set_block(0, x)
+                e.spmm(0, 1)
+                got[mode] = e.get_block(1)
+                e.set_block(1, np.full_like(x, 3.0))   # a second product must not depend on what the first left
+                e.spmm(0, 1)
+                assert e.get_block(1).tobytes() == got[mode].tobytes()
+            assert np.all(np.abs(got[mode] - want) <= (maxlen + 4) * np.finfo(float).eps * bound + 1e-300), mode
+        assert np.all(got["2"][np.diff(a.row_head_indexes) == 0] == 0)
+        # rows the regrouped form does not touch (up to 16 entries) come from the same kernel as before
+        short = np.diff(a.row_head_indexes) <= 16
+        assert got["2"][short].tobytes() == got["0"][short].tobytes()
+
+
 def test_block_run_on_a_power_law_graph_laplacian(gpu):
     """R-MAT graph Laplacian (hubs, isolated vertices): the block run against the numpy model, and the
     single-vector path with full reorthogonalisation (src/lanczos.c:156-167) on the top of the spectrum."""
