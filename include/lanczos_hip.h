@@ -495,6 +495,9 @@ int lanczos_hip_multi_step(lanczos_hip_multi *m);
 lanczos_hip_engine *lanczos_hip_multi_engine(lanczos_hip_multi *m, int slab);
 int lanczos_hip_multi_info(const lanczos_hip_multi *m, int *slabs, int *halo_exchange, int *overlapped, int *iterations,
                            int *reorth_steps);
+/* what the set-up of the slabs took (column remap on the host, upload, engine) and how many host threads shared it:
+ * one per slab on several devices (LANCZOS_HIP_MULTI_BUILD_THREADS=0: one slab after the other) */
+int lanczos_hip_multi_build_stats(const lanczos_hip_multi *m, double *seconds, int *host_threads);
 
 /* ---- thick restart -------------------------------------------------------
  * No counterpart in the reference, which keeps every vector of a run and stops at max_iter

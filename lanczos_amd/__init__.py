@@ -764,6 +764,7 @@ _hip.lanczos_hip_multi_step.argtypes = [C.c_void_p]
 _hip.lanczos_hip_multi_engine.argtypes = [C.c_void_p, C.c_int]
 _hip.lanczos_hip_multi_engine.restype = C.c_void_p
 _hip.lanczos_hip_multi_info.argtypes = [C.c_void_p] + [C.POINTER(C.c_int)] * 5
+_hip.lanczos_hip_multi_build_stats.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_int)]
 MULTI_LOOPBACK = 1
 
 
@@ -818,6 +819,11 @@ class MultiEngine:
         v = [C.c_int(0) for _ in range(5)]
         _check(_hip.lanczos_hip_multi_info(self._h, *[C.byref(x) for x in v]), "lanczos_hip_multi_info")
         return dict(zip(("slabs", "halo", "overlapped", "iterations", "reorth_steps"), (x.value for x in v)))
+
+    def build_stats(self) -> dict:
+        sec, thr = C.c_double(0), C.c_int(0)
+        _check(_hip.lanczos_hip_multi_build_stats(self._h, C.byref(sec), C.byref(thr)), "lanczos_hip_multi_build_stats")
+        return {"seconds": sec.value, "host_threads": thr.value}
 
     def slab_spmv_name(self, slab: int) -> str:
         return _hip.lanczos_hip_spmv_name(_hip.lanczos_hip_multi_engine(self._h, slab)).decode()

@@ -20,13 +20,16 @@ __global__ void k_balance_split(int64_t n, const RP *__restrict__ rp, int64_t un
         out[x] = x == 0 ? 0 : units;
         return;
     }
-    const double total = (double)rp[n] + (double)n;
+    // (rp may point into the middle of a matrix -- the rows of a slab that read nothing remote -- so offsets
+    // are taken relative to the first one)
+    const double first = (double)rp[0];
+    const double total = (double)rp[n] - first + (double)n;
     const double want = total * x / 8.0;
     int64_t lo = 0, hi = units;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         const int64_t r = mid * unit_rows < n ? mid * unit_rows : n;
-        if ((double)rp[r] + (double)r < want) lo = mid + 1;
+        if ((double)rp[r] - first + (double)r < want) lo = mid + 1;
         else hi = mid;
     }
     out[x] = lo;

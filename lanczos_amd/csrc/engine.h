@@ -101,6 +101,8 @@ struct Engine {
     int *d_carry_row = nullptr;        // merge SpMV: rows shared between tiles, two slots per tile
     double *d_carry_val = nullptr;
     long long *d_xcd_split = nullptr;  // [9] chunk ranges of the pipe kernel, equal entries per XCD
+    long long *d_xcd_split_in = nullptr;  // the same for the rows [split_in_lo, split_in_hi) of a split product
+    int64_t split_in_lo = -1, split_in_hi = -1;
     // tiled form of the matrix (LANCZOS_HIP_SPMV_PANEL): entries grouped by (row block, column panel)
     uint16_t *d_trow = nullptr;      // row in its 4096-row block (unpacked form)
     uint32_t *d_tcol = nullptr;      // column; packed form: row in block << 20 | column - d_tbase[chunk]

@@ -485,6 +485,7 @@ Engine::~Engine() {
     free_panels();
     free_dict();
     (void)hipFree(d_xcd_split);
+    (void)hipFree(d_xcd_split_in);
     (void)hipFree(d_tile_rows);
     (void)hipFree(d_carry_row);
     (void)hipFree(d_carry_val);
@@ -544,7 +545,8 @@ double Engine::spmv_bytes() const {
 
 // Rows [r_a, r_a + rows) of the product: the row offsets, y and xdot shifted, x and the entry arrays as
 // they are (column indices are absolute).  The merge and pipe forms hold precomputed splits of the
-// whole matrix and only take r_a = 0, rows = n.
+// whole matrix and only take r_a = 0, rows = n (the pipe form also takes the one sub-range whose XCD ranges
+// phase_spmv_begin has prepared in d_xcd_split_in).
 template <typename RP>
 static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, double *y_all, int *nparts,
                           int64_t r_a, int64_t rows, double *parts) {
@@ -588,19 +590,21 @@ static void launch_spmv_t(Engine *e, const double *x, const double *xdot_all, do
     }
     if (e->spmv_kind == LANCZOS_HIP_SPMV_PIPE || e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT) {
         const int lr = e->log2r;
-        const int64_t groups = (e->n + (1 << lr) - 1) >> lr;
+        const int64_t groups = (rows + (1 << lr) - 1) >> lr;
         const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
         int blocks = (int)std::min<int64_t>(e->max_blocks, round_up(chunks, 8));
         *nparts = blocks;
         const bool nt = e->spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT;
+        // the XCD ranges of the rows in hand: the whole matrix, or the rows of a split product
+        const long long *split = (r_a == 0 && rows == e->n) ? e->d_xcd_split : e->d_xcd_split_in;
 #define LZ_PIPE_CASE(LR)                                                                                       \
     case LR:                                                                                                   \
         if (nt)                                                                                                \
-            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, true>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,   \
-                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials, e->d_xcd_split);             \
+            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, true>), dim3(blocks), dim3(kBlock), 0, e->stream, rows,   \
+                               rp, e->d_col, e->d_val, x, xdot, y, parts, split);                              \
         else                                                                                                   \
-            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, false>), dim3(blocks), dim3(kBlock), 0, e->stream, e->n,  \
-                               rp, e->d_col, e->d_val, x, xdot, y, e->d_partials, e->d_xcd_split);             \
+            hipLaunchKernelGGL((k_spmv_pipe<RP, LR, false>), dim3(blocks), dim3(kBlock), 0, e->stream, rows,  \
+                               rp, e->d_col, e->d_val, x, xdot, y, parts, split);                              \
         break;
         switch (lr) {
             LZ_PIPE_CASE(6)
@@ -819,7 +823,7 @@ int Engine::launch_spmv_edges(int64_t lo, int64_t hi, double *parts_out, int *np
 int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
     if (int rc = check_can_step()) return rc;
     if (!can_split_product())
-        return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary, rows, stream or "
+        return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary, rows, pipe, stream or "
                     "vector SpMV");
     if (b_lo < 0 || b_hi > n || b_lo > b_hi) return fail("lanczos_hip_phase_spmv_begin: bad row range");
     ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
@@ -830,6 +834,23 @@ int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
         // the interior rows alone, from a multiple of 64 (the rows form's 64-row groups were sized on those)
         b_lo = std::min(round_up(b_lo, 64), b_hi);
         alpha_count = 0;
+        const bool pipe = spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT;
+        if (pipe && b_hi > b_lo && (b_lo != split_in_lo || b_hi != split_in_hi)) {
+            // XCD ranges of equal entry counts for these rows (the same range every iteration: computed once)
+            const int64_t rows_in = b_hi - b_lo;
+            const int64_t groups = (rows_in + (1 << log2r) - 1) >> log2r;
+            const int64_t chunks = (groups + kWavesPerBlock - 1) / kWavesPerBlock;
+            if (!d_xcd_split_in) HIP_TRY(hipMalloc(&d_xcd_split_in, sizeof(long long) * 9));
+            if (rp64)
+                hipLaunchKernelGGL((k_balance_split<int64_t>), dim3(1), dim3(64), 0, stream, rows_in,
+                                   (const int64_t *)d_rp + b_lo, (int64_t)kWavesPerBlock << log2r, chunks, d_xcd_split_in);
+            else
+                hipLaunchKernelGGL((k_balance_split<int32_t>), dim3(1), dim3(64), 0, stream, rows_in,
+                                   (const int32_t *)d_rp + b_lo, (int64_t)kWavesPerBlock << log2r, chunks, d_xcd_split_in);
+            HIP_TRY(hipGetLastError());
+            split_in_lo = b_lo;
+            split_in_hi = b_hi;
+        }
         if (b_hi > b_lo) {
             if (rp64)
                 launch_spmv_t<int64_t>(this, vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi - b_lo, d_partials);
@@ -846,7 +867,8 @@ int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
 bool Engine::can_split_product() const {
     return slab && !x_ext && nnz > 0 &&
            (spmv_kind == LANCZOS_HIP_SPMV_DICT || spmv_kind == LANCZOS_HIP_SPMV_ROWS ||
-            spmv_kind == LANCZOS_HIP_SPMV_STREAM || spmv_kind == LANCZOS_HIP_SPMV_VECTOR);
+            spmv_kind == LANCZOS_HIP_SPMV_STREAM || spmv_kind == LANCZOS_HIP_SPMV_VECTOR ||
+            spmv_kind == LANCZOS_HIP_SPMV_PIPE || spmv_kind == LANCZOS_HIP_SPMV_PIPE_NT);
 }
 
 // The remote entries have arrived: the rows that read them, then the reductions as phase_spmv.

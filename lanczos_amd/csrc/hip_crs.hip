@@ -132,8 +132,12 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
         int halo = 0, over = 0;
         if (lanczos_hip_multi_set_start_seed(mg, seed) != 0) goto cleanup;
         lanczos_hip_multi_info(mg, NULL, &halo, &over, NULL, NULL);
-        fprintf(stderr, "[INIT] name=row_slabs count=%d transport=%s exchange=%s overlapped=%d\n", std::max(ngpu, 1),
-                loopback ? "loopback" : "rccl", halo ? "halo" : "allgather", over);
+        double slab_sec = 0.0;
+        int slab_threads = 1;
+        lanczos_hip_multi_build_stats(mg, &slab_sec, &slab_threads);
+        fprintf(stderr, "[INIT] name=row_slabs count=%d transport=%s exchange=%s overlapped=%d sec=%.6f host_threads=%d\n",
+                std::max(ngpu, 1), loopback ? "loopback" : "rccl", halo ? "halo" : "allgather", over, slab_sec,
+                slab_threads);
     } else {
         std::vector<double> v0(dimension);
         lanczos_hip_gaussian_fill(seed, 0, (int64_t)dimension, v0.data());

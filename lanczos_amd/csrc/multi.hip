@@ -25,8 +25,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 #include <new>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "engine.h"
@@ -158,6 +161,8 @@ struct lanczos_hip_multi {
     lanczos_hip_omega *omega = nullptr;               // selective mode: one tracker decides for all slabs
     double *h_sel = nullptr;                          // pinned: alpha_k, |w|^2 for that decision
     double last_beta = 0.0;
+    double build_sec = 0.0;  // column remap, upload and engine set-up of all slabs
+    int build_threads = 1;   // host threads that did it
 
     ~lanczos_hip_multi();
     // slab p's device becomes current (and is noted as the current slab: lz::check_affinity)
@@ -285,12 +290,11 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
     base.assign((size_t)P, 0);
     in_lo.assign((size_t)P, 0);
     in_hi.assign((size_t)P, 0);
-    bool all_split = halo;
-    std::vector<int64_t> cols, head;
+    // Streams and events first, one slab after the other (with the loopback transport every slab shares slab 0's
+    // stream); then every slab's column remap, upload and engine in a host thread of its own, so that the matrix
+    // of a whole node (16 GB of CRS arrays for 512^3) does not go through one thread and one copy queue.
     for (int p = 0; p < P; ++p) {
         M_TRY(use(p));
-        const int64_t r0 = bounds[(size_t)p], r1 = bounds[(size_t)p + 1], nl = r1 - r0;
-        const int64_t e0 = rp[r0], cnt = rp[r1] - rp[r0];
         if (loopback && p > 0) {
             stream[(size_t)p] = stream[0];
         } else {
@@ -301,8 +305,15 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
             M_HIP(hipEventCreateWithFlags(&ev_ready[(size_t)p], hipEventDisableTiming));
             M_HIP(hipEventCreateWithFlags(&ev_done[(size_t)p], hipEventDisableTiming));
         }
+    }
+    std::vector<char> can_split((size_t)P, 1);
+    auto build_slab = [&](int p) -> int {
+        M_TRY(use(p));
+        const int64_t r0 = bounds[(size_t)p], r1 = bounds[(size_t)p + 1], nl = r1 - r0;
+        const int64_t e0 = rp[r0], cnt = rp[r1] - rp[r0];
         M_HIP(hipMalloc(&red[(size_t)p], sizeof(double) * (size_t)(max_iter + 8)));
         M_HIP(hipMemsetAsync(red[(size_t)p], 0, sizeof(double) * (size_t)(max_iter + 8), stream[(size_t)p]));
+        std::vector<int64_t> cols, head;
         try {
             cols.resize((size_t)std::max<int64_t>(cnt, 1));
             head.resize((size_t)nl + 1);
@@ -342,7 +353,7 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
             first_in = last_lo_row + 1;
             end_in = first_hi_row;
             // worth computing the boundary rows twice only when they are few
-            if (first_in > end_in || first_in + (nl - end_in) > nl / 4) all_split = false;
+            if (first_in > end_in || first_in + (nl - end_in) > nl / 4) can_split[(size_t)p] = 0;
             o.n_ext = b + hl + hh;
             ld[(size_t)p] = round_up(o.n_ext, 2048);
             M_HIP(hipMalloc(&basis[(size_t)p], sizeof(double) * (size_t)ld[(size_t)p] * (size_t)nvec));
@@ -364,8 +375,40 @@ int lanczos_hip_multi::build(int ngpu, const int *devices, int64_t n_, int64_t n
         in_hi[(size_t)p] = end_in;
         M_TRY(lz::Engine::create(&eng[(size_t)p], nl, cnt, head.data(), cols.data(), va + e0, max_iter, &o));
         eng[(size_t)p]->affinity_id = p;
-        if (halo && !eng[(size_t)p]->can_split_product()) all_split = false;
+        if (halo && !eng[(size_t)p]->can_split_product()) can_split[(size_t)p] = 0;
+        return 0;
+    };
+    const auto t_build = std::chrono::steady_clock::now();
+    // LANCZOS_HIP_MULTI_BUILD_THREADS: 0 one slab after the other, 1 a thread per slab (the default on several
+    // devices; with the loopback transport the slabs share a device and a stream and are built in turn)
+    const char *thr_env = getenv("LANCZOS_HIP_MULTI_BUILD_THREADS");
+    const bool threaded = P > 1 && (thr_env ? atoi(thr_env) != 0 : !loopback);
+    if (threaded) {
+        std::vector<int> rcs((size_t)P, 0);
+        std::vector<std::string> msgs((size_t)P);
+        std::vector<std::thread> workers;
+        try {
+            for (int p = 0; p < P; ++p)
+                workers.emplace_back([&, p] {
+                    rcs[(size_t)p] = lz::guarded("lanczos_hip_multi_create", [&]() -> int { return build_slab(p); });
+                    if (rcs[(size_t)p]) msgs[(size_t)p] = lz::last_error();  // the message is the failing thread's own
+                });
+        } catch (const std::exception &) {  // no more threads to be had: the slabs not started are built here
+            for (size_t p = workers.size(); p < (size_t)P; ++p) {
+                rcs[p] = build_slab((int)p);
+                if (rcs[p]) msgs[p] = lz::last_error();
+            }
+        }
+        for (auto &w : workers) w.join();
+        for (int p = 0; p < P; ++p)
+            if (rcs[(size_t)p]) return lz::fail("%s", msgs[(size_t)p].c_str());
+    } else {
+        for (int p = 0; p < P; ++p) M_TRY(build_slab(p));
     }
+    build_sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
+    build_threads = threaded ? P : 1;
+    bool all_split = halo;
+    for (int p = 0; p < P; ++p) all_split = all_split && can_split[(size_t)p];
     overlap = all_split && P > 1 && !(getenv("LANCZOS_HIP_MULTI_NO_OVERLAP") && atoi(getenv("LANCZOS_HIP_MULTI_NO_OVERLAP")));
     if (loopback) {
         M_TRY(use(0));
@@ -712,6 +755,13 @@ int lanczos_hip_multi_step(lanczos_hip_multi *m) {
 lanczos_hip_engine *lanczos_hip_multi_engine(lanczos_hip_multi *m, int slab) {
     if (!m || slab < 0 || slab >= m->P) return nullptr;
     return reinterpret_cast<lanczos_hip_engine *>(m->eng[(size_t)slab]);
+}
+
+int lanczos_hip_multi_build_stats(const lanczos_hip_multi *m, double *seconds, int *host_threads) {
+    if (!m) return lz::fail("lanczos_hip_multi_build_stats: NULL handle");
+    if (seconds) *seconds = m->build_sec;
+    if (host_threads) *host_threads = m->build_threads;
+    return 0;
 }
 
 int lanczos_hip_multi_info(const lanczos_hip_multi *m, int *slabs, int *halo_exchange, int *overlapped, int *iterations,

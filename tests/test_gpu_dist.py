@@ -195,7 +195,7 @@ def test_caller_owned_basis_is_validated(gpu):
         assert not basis[:, 3000:].any()
 
 
-@pytest.mark.parametrize("kind", ["auto", "rows", "stream", "vector"])
+@pytest.mark.parametrize("kind", ["auto", "rows", "stream", "vector", "pipe"])
 def test_split_product_matches_the_whole_one(gpu, kind):
     """phase_spmv_begin / phase_spmv_end (interior rows first, the rest after the exchange) against
     phase_spmv on the same vector: same y up to the order of a row's sum, same u.Au."""
@@ -258,7 +258,7 @@ def test_split_product_on_random_banded_matrices(gpu):
             rows = np.repeat(np.arange(n), lens)
             cols = np.clip(rows + rng.integers(-w, w + 1, head[-1]), 0, n - 1).astype(np.int64)
             a = la.CrsMatrix(rng.standard_normal(head[-1]), cols, head)
-            kinds = ["stream", "vector"] + (["rows"] if lens.max() <= 8 else [])
+            kinds = ["stream", "vector", "pipe"] + (["rows"] if lens.max() <= 8 else [])
         base = la.gather_base(n)
         basis = torch.zeros(3, base + 2048, dtype=torch.float64, device="cuda")
         v0 = rng.standard_normal(n)

@@ -126,6 +126,26 @@ def test_loopback_forced_allgather_and_unsplit_product(gpu, monkeypatch):
         assert np.array_equal(ra, np.concatenate([pa, qa]))
 
 
+def test_slabs_built_by_one_host_thread_each(gpu, monkeypatch):
+    """LANCZOS_HIP_MULTI_BUILD_THREADS=1: every slab's column remap, upload and engine in a host thread of its own
+    (the default on several devices; forced here on the loopback transport): same run as the slabs built in turn."""
+    a = la.synth_laplacian(3, 32)
+    v0 = la.gaussian_fill(4, 0, a.dimension)
+    runs = {}
+    for threads in ("0", "1"):
+        monkeypatch.setenv("LANCZOS_HIP_MULTI_BUILD_THREADS", threads)
+        with la.MultiEngine(a, 31, 4, reorth="full", loopback=True) as m:
+            st = m.build_stats()
+            assert st["host_threads"] == (4 if threads == "1" else 1) and st["seconds"] > 0
+            m.set_start(v0)
+            runs[threads] = m.run(30)
+    assert np.array_equal(runs["0"][0], runs["1"][0]) and np.array_equal(runs["0"][1], runs["1"][1])
+    # an error inside a slab's thread comes back as the call's own message
+    monkeypatch.setenv("LANCZOS_HIP_MULTI_BUILD_THREADS", "1")
+    with pytest.raises(la.LanczosHipError, match="rows SpMV needs every 64-row group"):
+        la.MultiEngine(la.synth_random_symmetric(40000, 40, 1), 5, 2, spmv="rows", loopback=True)
+
+
 def test_loopback_eight_slabs(gpu):
     """The slab count of a whole node: 4096-row slabs of a 32^3 Laplacian whose 1024-entry halos are just
     within half a slab (halo form), and the 32-row slabs of a 16 x 16 grid, too thin for it (all-gather form)."""
@@ -211,7 +231,7 @@ def test_dropin_honours_ngpu(gpu):
         res, out, err = _dropin(a, 4, 101, 0.0, {"LANCZOS_HIP_NGPU": "3", "LANCZOS_HIP_MULTI_LOOPBACK": "1",
                                                  "LANCZOS_HIP_REORTH": reorth, "LANCZOS_HIP_JSON": "1"})
         assert res["rc"] == 0 and rel_err(res["eig"], oo.eigenvalues) < 1e-10, reorth
-        assert "[INIT] name=row_slabs count=3 transport=loopback exchange=halo" in err
+        assert "[INIT] name=row_slabs count=3 transport=loopback exchange=halo" in err and " sec=" in err
         step_lines = [ln for ln in out.splitlines() if ln[:1].isdigit() and "\t" in ln]
         assert len(step_lines) == 100 and "Reached max iterations (101)" in out
         assert step_lines[49] == "50\t" + "\t".join(f"{x:.7f}" for x in oo.ritz_hist[49]) + "\t"
