@@ -51,10 +51,15 @@ def algorithmic_bytes(n: int, nnz: int) -> dict:
             "iter_moved": b_spmv + 32 * n}
 
 
-def gather_ceiling(kind: str, nnz: int, spmv_seconds: float):
+def gather_ceiling(kind: str, kernel: str, n: int, nnz: int, spmv_seconds: float):
     """The gather-bound SpMV forms against the L2s' measured line rate instead of the HBM roofline:
     L2 requests per SpMV = nnz x the requests-per-entry ratio that the PMC passes counted for this
-    form (TCC_REQ_sum, profiles/gather_requests.json), over the SpMV's time.  None without a record."""
+    form (TCC_REQ_sum, profiles/gather_requests.json), over the SpMV's time.  None without a record,
+    for any other kernel than the tiled form the record was counted on (a matrix whose x fits the
+    caches runs on the row-wise forms, whose gathers mostly hit in L1), and for a vector of less than
+    32 MiB (the L2s' total: below it the counted ratio of requests per entry does not hold)."""
+    if not kernel.startswith("panel") or 8 * n < 32 * 2**20:
+        return None
     try:
         rec = json.load(open(os.path.join(HERE, "profiles", "gather_requests.json")))[kind]
     except (OSError, ValueError, KeyError):
@@ -214,7 +219,7 @@ def random_symmetric_section(la, torch, rows: int, steps: int = 100) -> dict:
         "spmv_GBps": spmv_gbps,
         "spmv_frac_of_hbm_peak": spmv_gbps / HBM_PEAK_GBPS,
         # one L2 request per gather: the ceiling this kernel runs against
-        "gather_ceiling": gather_ceiling("random_symmetric", nnz, prof["spmv"]["ms"] * 1e-3 / steps),
+        "gather_ceiling": gather_ceiling("random_symmetric", name, n, nnz, prof["spmv"]["ms"] * 1e-3 / steps),
         "generate_s": t_gen,
     }
 
@@ -251,7 +256,7 @@ def power_law_section(la, torch, scale: int, steps: int = 50, block_steps: int =
         "spmv_kernel": name,
         "spmv_avg_ms": prof["spmv"]["ms"] / steps,
         "spmv_G_entries_per_s": nnz * steps / (prof["spmv"]["ms"] * 1e-3) / 1e9,
-        "gather_ceiling": gather_ceiling("power_law_graph", nnz, prof["spmv"]["ms"] * 1e-3 / steps),
+        "gather_ceiling": gather_ceiling("power_law_graph", name, n, nnz, prof["spmv"]["ms"] * 1e-3 / steps),
         "generate_s": t_gen,
     }
     if block_steps > 0:

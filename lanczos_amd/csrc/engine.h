@@ -194,6 +194,7 @@ struct Engine {
     int launch_scale(const double *parts, int cnt);
     int flush_lazy();
     int launch_dots(int l0, int l1, double *red_out);
+    int launch_recur_dots(const double *alpha_parts, int alpha_cnt, int l0, int l1, double *red_out);
     int launch_update(int l0, int l1, const double *h, int *nparts);
     bool red_has_norm = false;  // phase_recur left w.w behind the coefficients in the caller's buffer
     int phase_spmv(double *red);

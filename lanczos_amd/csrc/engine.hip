@@ -695,6 +695,29 @@ int Engine::launch_dots(int l0, int l1, double *red_out) {
     return 0;
 }
 
+// The recurrence of iteration k (k > 0) and red_out[l - l0] = V_l . w for l in [l0, l1) in one sweep over w; the
+// first kMaxDotsSegment basis vectors ride with the recurrence, any further ones take plain k_dots launches.
+int Engine::launch_recur_dots(const double *alpha_parts, int alpha_cnt, int l0, int l1, double *red_out) {
+    const int blocks = tile_blocks();
+    double *ahost = h_hist ? h_hist + 2 * (size_t)k : nullptr;
+    const int s1 = std::min(l1, l0 + kMaxDotsSegment);
+    const int nl = s1 - l0;
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_DOTS, 8.0 * (double)n * nl + 32.0 * (double)n);
+        hipLaunchKernelGGL(k_recur_dots, dim3(blocks), dim3(kBlock), sizeof(double) * (kWavesPerBlock * nl + kWavesPerBlock),
+                           stream, (const double2 *)d_V, ldv / 2, l0, s1, (double2 *)vec(k + 1), (const double2 *)vec(k),
+                           (const double2 *)vec(k - 1), npad / 2, alpha_parts, alpha_cnt, (const double *)(d_scal + 1),
+                           d_hpart, hstride, d_alpha + k, ahost);
+    }
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (double)blocks * nl);
+        hipLaunchKernelGGL(k_hreduce, dim3(nl), dim3(kBlock), 0, stream, d_hpart, hstride, blocks, red_out);
+    }
+    HIP_TRY(hipGetLastError());
+    if (s1 < l1) return launch_dots(s1, l1, red_out + nl);
+    return 0;
+}
+
 int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
     const int blocks = tile_blocks();
     *nparts = blocks;
@@ -1070,10 +1093,31 @@ int Engine::enqueue_iteration() {
         if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
         return 0;
     }
-    if (int rc = launch_recur(d_partials, alpha_count)) return rc;
-    if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) return selective_tail();
     int l0, l1;
     reorth_range(&l0, &l1);
+    // recurrence and the pass's dot products in one sweep over w whenever a blocked pass follows the recurrence
+    // (LANCZOS_HIP_FUSE_RECUR=0: two launches; same bits either way)
+    const char *fuse_env = getenv("LANCZOS_HIP_FUSE_RECUR");  // read per iteration: tests compare the two forms
+    const bool fuse = !(fuse_env && atoi(fuse_env) == 0);
+    const bool blocked = reorth == LANCZOS_HIP_REORTH_FULL || reorth == LANCZOS_HIP_REORTH_FULL2 ||
+                         reorth == LANCZOS_HIP_REORTH_CUDA_COMPAT;
+    // Only while the pass is short: at k = 10 the one sweep saves 0.026 ms of 0.30 (256^3), but with 150 basis
+    // vectors behind it the stores of w inside the sweep cost the basis stream 0.15 ms more than k_recur's own
+    // pass took (3.18 ms against 2.95 + 0.08); measured break-even near 30 vectors.
+    constexpr int kFuseMaxVectors = 32;
+    if (fuse && blocked && k > 0 && l1 > l0 && l1 - l0 <= kFuseMaxVectors) {
+        reorth_steps += 1;
+        int nparts = 0;
+        if (int rc = launch_recur_dots(d_partials, alpha_count, l0, l1, d_red)) return rc;
+        if (int rc = launch_update(l0, l1, d_red, &nparts)) return rc;
+        if (reorth == LANCZOS_HIP_REORTH_FULL2) {
+            if (int rc = launch_dots(l0, l1, d_red)) return rc;
+            if (int rc = launch_update(l0, l1, d_red, &nparts)) return rc;
+        }
+        return launch_scale(norm_parts(k), norm_count);
+    }
+    if (int rc = launch_recur(d_partials, alpha_count)) return rc;
+    if (reorth == LANCZOS_HIP_REORTH_SELECTIVE) return selective_tail();
     if (l1 > l0) reorth_steps += 1;
     if (reorth == LANCZOS_HIP_REORTH_MGS) {
         // exact order of src/lanczos.c:156-167: one basis vector at a time

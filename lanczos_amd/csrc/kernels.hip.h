@@ -1221,6 +1221,62 @@ k_dots(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, const double
         hpart[(size_t)j * hstride + blockIdx.x] = (hs[j] + hs[nl + j]) + (hs[2 * nl + j] + hs[3 * nl + j]);
 }
 
+// The three-term recurrence and the first half of the reorthogonalisation pass in one sweep: a workgroup
+// forms its tile of w <- (w - beta v_{k-1}) - alpha v_k (the expression of k_recur), writes it, and keeps it in
+// registers while V_{l0..l1-1} stream past it as in k_dots.  Same tiles, same grid and the same order of
+// every sum as k_recur followed by k_dots, so the bits are theirs; what is saved is k_recur's own pass over
+// w, v_k and v_{k-1} (32 n bytes become the 16 n of reading v_k and writing w here) and one launch.
+__global__ void __launch_bounds__(kBlock)
+k_recur_dots(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *__restrict__ w,
+             const double2 *__restrict__ vk, const double2 *__restrict__ vprev, int64_t n2,
+             const double *__restrict__ alpha_parts, int alpha_count, const double *__restrict__ beta_p,
+             double *__restrict__ hpart, int hstride, double *__restrict__ alpha_hist, double *alpha_host) {
+    extern __shared__ double hs[];  // [4][nl], then the four doubles of the alpha sum
+    const int nl = l1 - l0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double alpha = sum_partials(alpha_parts, alpha_count, hs + nl * kWavesPerBlock);
+    const double beta = beta_p[0];
+    for (int j = threadIdx.x; j < nl * kWavesPerBlock; j += kBlock) hs[j] = 0.0;
+    __syncthreads();
+    double *myhs = hs + wave * nl;
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    for (int64_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 wt[kEPT2], p[kEPT2], q[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) p[u] = vprev[base + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) q[u] = vk[base + u * kBlock];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) {
+            wt[u].x = (wt[u].x - beta * p[u].x) - alpha * q[u].x;
+            wt[u].y = (wt[u].y - beta * p[u].y) - alpha * q[u].y;
+            w[base + u * kBlock] = wt[u];
+        }
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+#pragma unroll 2
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            double s = 0.0;
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                const double2 v = ld_stream(vl + u * kBlock);
+                s += v.x * wt[u].x + v.y * wt[u].y;
+            }
+            s = wave_sum(s);
+            if (lane == 0) myhs[l] += s;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nl; j += kBlock)
+        hpart[(size_t)j * hstride + blockIdx.x] = (hs[j] + hs[nl + j]) + (hs[2 * nl + j] + hs[3 * nl + j]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        alpha_hist[0] = alpha;
+        if (alpha_host) alpha_host[0] = alpha;
+    }
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_update(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *__restrict__ w,
          int64_t n2, const double *__restrict__ h, double *__restrict__ partials) {

@@ -85,10 +85,37 @@ def recur_form(sizes):
     return out
 
 
+def fuse_form(sizes):
+    """300 (and 20) steps with full reorthogonalisation: recurrence + dots in one sweep (while the pass is short) against
+    two launches; two rounds each, alternating."""
+    out = {}
+    for N in sizes:
+        a = la.synth_laplacian(3, N)
+        v0 = la.gaussian_fill(123456789, 0, a.dimension)
+        for steps in (20, 300):
+            with la.Engine(a, steps + 1, reorth="full", profile=True) as e:
+                for rnd in range(2):
+                    for tag, env in (("two", {"LANCZOS_HIP_FUSE_RECUR": "0"}), ("fused", {"LANCZOS_HIP_FUSE_RECUR": "1"})):
+                        os.environ.update(env)
+                        e.set_start(v0)
+                        e.run(5)
+                        e.set_start(v0)
+                        e.profile_reset()
+                        import time
+                        t0 = time.perf_counter()
+                        e.run(steps)
+                        dt = time.perf_counter() - t0
+                        p = e.profile()
+                        rec = {"its_per_s": steps / dt, **{k: round(v["ms"] / steps, 4) for k, v in p.items()}}
+                        out.setdefault(f"{N}^3 {steps} {tag}", []).append(rec)
+                        print(N, steps, tag, rec, flush=True)
+    return out
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     sizes = [int(s) for s in sys.argv[2:]] or ([256] if what == "rows" else [256, 512])
-    res = rows_form(sizes) if what == "rows" else recur_form(sizes)
+    res = rows_form(sizes) if what == "rows" else fuse_form(sizes) if what == "fuse" else recur_form(sizes)
     tag = os.environ.get("R3_TAG", what)
     os.makedirs("gpurun_out/r3k", exist_ok=True)
     json.dump(res, open(f"gpurun_out/r3k/{tag}.json", "w"), indent=1)

@@ -846,10 +846,10 @@ def test_lanczos_takes_a_custom_matvec_plugin(gpu):
 def test_rows_spmv_with_tiles_loaded_straight_into_lds_gives_the_same_bits(gpu, monkeypatch):
     """LANCZOS_HIP_ROWS_DMA=1 (read at every launch): the row-wise CRS kernel whose col/val tiles go from
     memory into LDS without passing through registers; same sums in the same order as the register-staged
-    form, on grids of one, two and three dimensions, an awkward size and rows longer than one chunk."""
+    form, on grids of one, two and three dimensions, awkward sizes and a band with random values."""
     import scipy.sparse as sp
     rng = np.random.default_rng(5)
-    band = sp.diags([rng.standard_normal(5000 - abs(k)) for k in range(-6, 7)], list(range(-6, 7))).tocsr()  # 13 per row
+    band = sp.diags([rng.standard_normal(5000 - abs(k)) for k in range(-3, 4)], list(range(-3, 4))).tocsr()  # 7 per row
     cases = [la.synth_laplacian(3, 33), la.synth_laplacian(2, 129), la.synth_laplacian(1, 70001),
              la.CrsMatrix(band.data, band.indices.astype(np.int64), band.indptr.astype(np.int64))]
     with plain_rows():
@@ -864,6 +864,30 @@ def test_rows_spmv_with_tiles_loaded_straight_into_lds_gives_the_same_bits(gpu, 
                 monkeypatch.delenv("LANCZOS_HIP_ROWS_DMA")
             assert y0.tobytes() == y1.tobytes()
             assert np.max(np.abs(y0 - oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x))) < 1e-12
+
+
+@pytest.mark.parametrize("reorth", ["full", "full2", "cuda_compat"])
+def test_recurrence_fused_with_the_dot_products_gives_the_same_bits(gpu, monkeypatch, reorth):
+    """The three-term recurrence (src/lanczos.c:150-154) and the first half of the reorthogonalisation pass
+    (src/lanczos.c:156-167 as a blocked product) run as one sweep over w; LANCZOS_HIP_FUSE_RECUR=0 keeps the two
+    launches.  Same tiles and the same order of every sum: alpha and beta equal bit for bit, on a size with
+    several tiles per workgroup and on one smaller than a tile."""
+    for a in (la.synth_laplacian(3, 40), la.synth_laplacian(1, 700), la.synth_random_symmetric(30000, 6, 3)):
+        v0 = la.gaussian_fill(5, 0, a.dimension)
+        runs = {}
+        for fuse in ("1", "0"):
+            monkeypatch.setenv("LANCZOS_HIP_FUSE_RECUR", fuse)
+            with la.Engine(a, 41, reorth=reorth, profile=True) as e:
+                e.set_start(v0)
+                runs[fuse] = e.run(40)
+                launches = e.profile()["recur"]["launches"]
+                # fused while the pass covers at most 32 vectors: iteration 0 has none (cuda_compat: 0..2), then
+                # iterations up to k = 32 (34) ride with the dot products, the rest launch k_recur again
+                assert launches == (40 if fuse == "0" else 1 + 7 if reorth != "cuda_compat" else 3 + 5)
+        assert runs["1"][0].tobytes() == runs["0"][0].tobytes() and runs["1"][1].tobytes() == runs["0"][1].tobytes()
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 41, 0.0,
+                               "cuda_compat" if reorth == "cuda_compat" else "full")
+        assert rel_err(la.ritz_values(*runs["1"], 40, 4), o.eigenvalues) < 1e-10
 
 
 def test_a_host_operator_has_no_checkpoint_and_no_device_product(gpu, tmp_path):
