@@ -17,7 +17,7 @@ import csv
 import json
 import sys
 
-CLASS_OF = (("k_spmv", "spmv"), ("k_recur", "recur"), ("k_scale", "scale"), ("k_dots", "dots"),
+CLASS_OF = (("k_spmv", "spmv"), ("k_recur_dots", "dots"), ("k_recur", "recur"), ("k_scale", "scale"), ("k_dots", "dots"),
             ("k_update", "update"))
 
 
@@ -40,9 +40,13 @@ def main():
                 "| kernel | launches | FETCH_SIZE KiB (avg) | read MB (2x) | WRITE_SIZE KiB (avg) | write MB |",
                 "|---|---|---|---|---|---|"]
         agg = collections.defaultdict(lambda: {"f": [], "w": []})
+        by_class = collections.defaultdict(lambda: {"f": [], "w": []})   # (dispatch id, value), several kernels a class
         for path, key in ((sys.argv[3], "f"), (sys.argv[4], "w")):
             for r in csv.DictReader(open(path)):
                 agg[short(r["Kernel_Name"])][key].append(float(r["Counter_Value"]))
+                cls = next((c for name, c in CLASS_OF if name in r["Kernel_Name"]), None)
+                if cls:
+                    by_class[cls][key].append((int(r["Dispatch_Id"]), float(r["Counter_Value"])))
         for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]["f"])):
             if not v["f"]:
                 continue
@@ -55,15 +59,13 @@ def main():
             bench = json.loads(open(sys.argv[9]).read().strip().splitlines()[-1])
             alg, launches = bench["kernel_algorithmic_bytes_total"], bench["kernel_launches"]
             measured, ratio = {}, {}
-            for k, v in agg.items():
-                cls = next((c for key, c in CLASS_OF if key in k), None)
-                if cls is None or not v["f"] or not v["w"]:
-                    continue
+            for cls, v in by_class.items():
                 cnt = int(launches.get(cls, 0))
                 if cnt <= 0 or len(v["f"]) < cnt or len(v["w"]) < cnt:
                     continue
-                f, w = v["f"][-cnt:], v["w"][-cnt:]
-                measured[cls] = measured.get(cls, 0.0) + 2 * 1024 * sum(f) + 1024 * sum(w)
+                f = [x for _, x in sorted(v["f"])[-cnt:]]
+                w = [x for _, x in sorted(v["w"])[-cnt:]]
+                measured[cls] = 2 * 1024 * sum(f) + 1024 * sum(w)
             for cls, b in measured.items():
                 if alg.get(cls, 0) > 0:
                     ratio[cls] = b / alg[cls]
