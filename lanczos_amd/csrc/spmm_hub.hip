@@ -1,6 +1,6 @@
 // Sparse product of the block variant, Y = A X with X and Y n x 16 row-major (the block form of
-// src/crs.c:155-178), for the "hub" rows of a power-law graph: the few per cent of the rows (more than
-// 64 entries each) that hold most of the entries.
+// src/crs.c:155-178), for the "hub" rows of a power-law graph: the rows of more than a few entries (16 by
+// default), a quarter of the rows and nine tenths of the entries.
 //
 // Every entry of such a row gathers one 128-byte row of X from a table far larger than the caches, and the
 // row-wise kernels move one line per entry across the fabric (counted on an R-MAT graph of 2^24 vertices:
@@ -9,8 +9,8 @@
 // every one of the eight L2s caches the same lines.  Here the hub rows' entries are regrouped once, on the
 // device, by COLUMN CLASS -- a hash of the column, eight classes -- and class x is multiplied by workgroups
 // b with b % 8 == x, which the hardware places on one XCD: the eight L2s then hold disjoint eighths of X.
-// The columns are further split by popularity: the entries of the `hot` columns (a set sized to stay resident in the
-// L2s) are multiplied first, in a launch of their own; the others, which would only push them out, afterwards.
+// Optionally (degree_floor > 0; off by default, it measured no faster) the columns are also split by popularity:
+// the entries of the popular columns are multiplied first, in a launch of their own, the others afterwards.
 //
 // A (class, hub row) pair is a run of consecutive entries of the stream.  Eight lanes walk a slice of 256
 // entries and sum run by run; a run that lies inside its slice is stored as a partial row at once, a run
