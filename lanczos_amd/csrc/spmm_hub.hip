@@ -113,8 +113,18 @@ __device__ __forceinline__ d2v load_x(const double *p) {
 // b % 8 of them.  Eight lanes (lane c: columns 2c, 2c + 1 of X and Y) own a slice of kSlice entries.
 template <bool COLD>
 __global__ void __launch_bounds__(kT)
-k_spmm16_hub(HubLayout lay, int64_t H, int slice_log2, const HubEntry *__restrict__ ent, const double *__restrict__ X,
+k_spmm16_hub(HubLayout lay, int64_t H, int slice_log2, int nt, const HubEntry *__restrict__ ent, const double *__restrict__ X,
              double *__restrict__ part, int *__restrict__ carry_h, double *__restrict__ carry_val) {
+    // nt & 1: the stream is read past the caches' keep-lists, nt & 2: the partial rows are written that way: neither
+    // is read again by this kernel, and every line they would occupy in an L2 is a row of X less
+    auto load_entry = [&](int64_t i) -> HubEntry {
+        if (nt & 1) return __builtin_bit_cast(HubEntry, __builtin_nontemporal_load(reinterpret_cast<const d2v *>(ent + i)));
+        return ent[i];
+    };
+    auto store_row = [&](double *p, d2v v) {
+        if (nt & 2) __builtin_nontemporal_store(v, reinterpret_cast<d2v *>(p));
+        else *reinterpret_cast<d2v *>(p) = v;
+    };
     const int64_t kSlice = (int64_t)1 << slice_log2;
     const int lane = threadIdx.x & 63, c = lane & 7, g = lane >> 3, wave = threadIdx.x >> 6;
     const int vc = (int)(blockIdx.x & 7) + (COLD ? 8 : 0);
@@ -139,18 +149,18 @@ k_spmm16_hub(HubLayout lay, int64_t H, int slice_log2, const HubEntry *__restric
                 const int w = head ? 0 : 1;
                 if (w) carry1 = cur;
                 else carry0 = cur;
-                *reinterpret_cast<d2v *>(carry_val + (slot + w) * kCols + 2 * c) = acc;
+                store_row(carry_val + (slot + w) * kCols + 2 * c, acc);
             } else {
-                *reinterpret_cast<d2v *>(part + ((int64_t)vc * H + cur) * kCols + 2 * c) = acc;
+                store_row(part + ((int64_t)vc * H + cur) * kCols + 2 * c, acc);
             }
             first = false;
         };
         HubEntry nxt = HubEntry{0, -1, 0.0};
-        if (a + c < b) nxt = ent[a + c];
+        if (a + c < b) nxt = load_entry(a + c);
         for (int64_t p = a; p < b; p += 8) {
             const HubEntry now = nxt;
             nxt = HubEntry{0, -1, 0.0};
-            if (p + 8 + c < b) nxt = ent[p + 8 + c];
+            if (p + 8 + c < b) nxt = load_entry(p + 8 + c);
             d2v x[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -456,12 +466,14 @@ int hub_build(lz::Engine *base, const int *d_rows_a, int count_a, const int *d_r
 
 int hub_spmm(const HubStream &hs, hipStream_t st, int cus, const double *X, double *Y) {
     if (!hs.ready()) return lz::fail("lanczos_hip_block: no hub stream");
+    int nt = 0;
+    if (const char *e = getenv("LANCZOS_HIP_SPMM_NT")) nt = atoi(e);
     const int blocks = std::max(cus, 8) / 8 * 8 * 8;  // eight workgroups per CU, a multiple of eight
     if (hs.lay.e_lo[8] > hs.lay.e_lo[0])
-        hipLaunchKernelGGL((k_spmm16_hub<false>), dim3(blocks), dim3(kT), 0, st, hs.lay, hs.H, hs.slice_log2, (const HubEntry *)hs.d_ent, X,
+        hipLaunchKernelGGL((k_spmm16_hub<false>), dim3(blocks), dim3(kT), 0, st, hs.lay, hs.H, hs.slice_log2, nt, (const HubEntry *)hs.d_ent, X,
                            hs.d_part, hs.d_carry_h, hs.d_carry_val);
     if (hs.lay.e_lo[16] > hs.lay.e_lo[8])
-        hipLaunchKernelGGL((k_spmm16_hub<true>), dim3(blocks), dim3(kT), 0, st, hs.lay, hs.H, hs.slice_log2, (const HubEntry *)hs.d_ent, X,
+        hipLaunchKernelGGL((k_spmm16_hub<true>), dim3(blocks), dim3(kT), 0, st, hs.lay, hs.H, hs.slice_log2, nt, (const HubEntry *)hs.d_ent, X,
                            hs.d_part, hs.d_carry_h, hs.d_carry_val);
     const int fb = (int)std::min<int64_t>((int64_t)cus * 8, (hs.slices + kT / 8 - 1) / (kT / 8));
     hipLaunchKernelGGL(k_hub_fixup, dim3(std::max(fb, 1)), dim3(kT), 0, st, hs.lay, hs.H, hs.slices,
