@@ -76,3 +76,12 @@ cd $root
 if grep -q "AddressSanitizer" $out/log.txt; then echo "sanitizer reports:"; grep -c "ERROR: AddressSanitizer" $out/log.txt; fi
 grep "rc=" $out/log.txt | sort | uniq -c
 grep -B1 "rc=[1-9]" $out/log.txt | head -40 || true
+# the C ABI beyond the driver (engine handle, block variant, slabs) under the same sanitizer build
+echo "== api_check" >> $out/log.txt
+timeout -k 10 300 $root/lanczos_amd/bin/api_check_asan $out > $out/api_check.txt 2>&1
+echo "   api_check rc=$?" | tee -a $out/log.txt
+tail -40 $out/api_check.txt
+# once more with the block variant's regrouped stream forced on (the small power-law matrix would not ask for it)
+timeout -k 10 300 env LANCZOS_HIP_SPMM_HUB=2 $root/lanczos_amd/bin/api_check_asan $out > $out/api_check_hub.txt 2>&1
+echo "   api_check (hub stream forced) rc=$?" | tee -a $out/log.txt
+grep "block variant\|ok$\|failed" $out/api_check_hub.txt
