@@ -13,7 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include "lanczos_host.h"
+#include "../../include/lanczos_host.h"
 
 static int failures = 0;
 #define CHECK(cond, ...)                                                   \

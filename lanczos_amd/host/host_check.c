@@ -15,7 +15,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
-#include "lanczos_host.h"
+#include "../../include/lanczos_host.h"
 
 static int failures = 0;
 #define CHECK(cond, ...)                         \

@@ -942,6 +942,20 @@ def test_c_program_with_a_matrix_free_plugin(gpu):
     assert len(eig) == 3 and np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12   # printed at %.12f
 
 
+def test_c_program_walks_the_abi(gpu, tmp_path):
+    """lanczos_amd/bin/api_check: a C program on include/lanczos_hip.h alone -- eight SpMV forms against each other on
+    two Laplacians, five on a random and a power-law matrix (alpha/beta of 30 steps, products), Ritz vectors, a
+    checkpoint resumed bit for bit, thick restart, the device COO->CRS build byte for byte the host's
+    (src/crs.c:8-153), the block variant's product against the host product (src/crs.c:155-178), 2 and 5 slabs
+    against one engine.  Once as it is, once with the block variant's regrouped stream forced on."""
+    exe = os.path.join(ROOT, "lanczos_amd", "bin", "api_check")
+    for extra in ({}, {"LANCZOS_HIP_SPMM_HUB": "2"}):
+        p = subprocess.run([exe, str(tmp_path)], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+        assert "api_check: ok" in p.stdout
+        assert p.stdout.count(" agrees ") == 22 and "refused" not in p.stderr
+
+
 def test_driver_binary_on_triplet_file(gpu, tmp_path):
     """main -> read_mat_coo_incremental -> convert_from_coo(swap=1) -> lanczos_hip_crs."""
     n = 10000
