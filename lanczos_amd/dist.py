@@ -559,6 +559,12 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
     dt = float(t.item())
     alpha, beta = runner.history()
     prof = runner.engine.e.profile()
+    # achieved SpMV bandwidth of the timed run: every rank's kernel on its own slab (the bytes of the slab's format over
+    # the kernel's HIP-event time), summed over the ranks
+    mine = prof["spmv"]["bytes"] / (prof["spmv"]["ms"] * 1e-3) / 1e9 if prof["spmv"]["ms"] > 0 else 0.0
+    bw = torch.tensor([mine], dtype=torch.float64, device="cuda")
+    dist.all_reduce(bw)
+    spmv_gbps_all = float(bw.item())
     out = None
     if rank == 0:
         bytes_ = algorithmic_bytes(n, nnz)
@@ -594,6 +600,9 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
                 "frac": achieved / hbm_peak, "traffic": None, "launches": p["launches"],
                 "note": "rank 0's slab; per-GPU figure",
             },
+            "spmv_hbm_GBps": spmv_gbps_all,
+            "spmv_hbm_GBps_per_gpu": spmv_gbps_all / world,
+            "spmv_hbm_kernel": runner.engine.e.spmv_name,
             "crs_charged_bytes_per_iter_no_reorth": bytes_["iter_charged"],
             "kernel_ms_total_rank0": {k_: v["ms"] for k_, v in prof.items()},
             "ritz_lowest4": [float(x) for x in ritz],

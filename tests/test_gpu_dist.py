@@ -128,6 +128,7 @@ def test_bench_distributed_code_path_with_one_rank(gpu):
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["steps"] == 40 and out["value"] > 0
+    assert 0 < out["spmv_hbm_GBps"] <= 8000.0 and out["spmv_hbm_kernel"]   # the metric's second half: achieved SpMV GB/s
     assert out["strong_scaling_laplacian"]["iters_per_s"] > 0 and out["random_symmetric"]["iters_per_s"] > 0
     assert out["converged_run"]["steps"] == 60 and out["converged_run"]["seconds"] > 0
     inproc = out["in_process_rccl"]                    # rank 0 driving the slabs through the library's own RCCL calls
