@@ -583,6 +583,27 @@ int lanczos_hip_block_project(lanczos_hip_block *b, int t0, int t1, int t_w,    
 int lanczos_hip_block_orthonormalise(lanczos_hip_block *b, int t, double *factor_out_host);
 int lanczos_hip_block_profile(const lanczos_hip_block *b, int cls, double *ms, int64_t *launches, double *bytes);
 void lanczos_hip_block_profile_reset(lanczos_hip_block *b);
+/*
+ * The block variant on row slabs, one host process over `ngpu` GPUs (no counterpart in the reference, which has
+ * neither; it must agree with lanczos_hip_block_* on one GPU, to rounding: sums over the rows are taken slab by
+ * slab).  The whole matrix is passed; slab p takes rows [p n / ngpu, (p + 1) n / ngpu) with its columns renumbered
+ * into a table of X that an all-gather fills every block step (n x 16 doubles), and the 16 x 16 matrices the one-GPU
+ * engine sums over its rows are all-reduced over the slabs (four reductions per block step).  `flags`:
+ * LANCZOS_HIP_MULTI_LOOPBACK puts every slab on one device, copies and a summing kernel in place of RCCL.
+ */
+typedef struct lanczos_hip_block_multi lanczos_hip_block_multi;
+int lanczos_hip_block_multi_create(lanczos_hip_block_multi **out, int ngpu, const int *devices, int64_t n, int64_t nnz,
+                                   const int64_t *row_head_indexes, const int64_t *column_index, const double *values,
+                                   int max_steps, const lanczos_hip_options *opt, int flags);
+void lanczos_hip_block_multi_destroy(lanczos_hip_block_multi *m);
+int lanczos_hip_block_multi_set_start(lanczos_hip_block_multi *m, const double *x0_host);   /* n x 16, row-major */
+int lanczos_hip_block_multi_set_start_seed(lanczos_hip_block_multi *m, uint64_t seed);      /* as lanczos_hip_block_set_start_seed */
+int lanczos_hip_block_multi_run(lanczos_hip_block_multi *m, int steps);
+int lanczos_hip_block_multi_steps(const lanczos_hip_block_multi *m);
+int lanczos_hip_block_multi_slabs(const lanczos_hip_block_multi *m);
+int lanczos_hip_block_multi_tmatrix(lanczos_hip_block_multi *m, int steps, double *a_out, double *b_out);
+int lanczos_hip_block_multi_ritz(lanczos_hip_block_multi *m, int steps, int nth, double *eig_out);
+int lanczos_hip_block_multi_get_block(lanczos_hip_block_multi *m, int t, double *out_host); /* block Q_t, n x 16 */
 /* lowest nth eigenvalues of a dense symmetric n x n matrix (row-major, destroyed) */
 int lanczos_hip_sym_lowest_eigs(double *a, int n, int nth, double *eig);
 /* all eigenpairs of a small dense symmetric matrix (cyclic Jacobi): eig ascending, row i of vec

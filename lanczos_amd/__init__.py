@@ -393,6 +393,19 @@ _hip.lanczos_hip_block_orthonormalise.argtypes = [C.c_void_p, C.c_int, _dp]
 _hip.lanczos_hip_block_profile.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp]
 _hip.lanczos_hip_block_profile_reset.argtypes = [C.c_void_p]
 _hip.lanczos_hip_block_profile_reset.restype = None
+_hip.lanczos_hip_block_multi_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int), C.c_int64, C.c_int64, _ip, _ip,
+                                                _dp, C.c_int, C.POINTER(Options), C.c_int]
+_hip.lanczos_hip_block_multi_create.restype = C.c_int
+_hip.lanczos_hip_block_multi_destroy.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_multi_destroy.restype = None
+_hip.lanczos_hip_block_multi_set_start.argtypes = [C.c_void_p, _dp]
+_hip.lanczos_hip_block_multi_set_start_seed.argtypes = [C.c_void_p, C.c_uint64]
+_hip.lanczos_hip_block_multi_run.argtypes = [C.c_void_p, C.c_int]
+_hip.lanczos_hip_block_multi_steps.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_multi_slabs.argtypes = [C.c_void_p]
+_hip.lanczos_hip_block_multi_tmatrix.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+_hip.lanczos_hip_block_multi_ritz.argtypes = [C.c_void_p, C.c_int, C.c_int, _dp]
+_hip.lanczos_hip_block_multi_get_block.argtypes = [C.c_void_p, C.c_int, _dp]
 _hip.lanczos_hip_sym_lowest_eigs.argtypes = [_dp, C.c_int, C.c_int, _dp]
 
 
@@ -512,6 +525,76 @@ class BlockEngine:
 
     def profile_reset(self):
         _hip.lanczos_hip_block_profile_reset(self._h)
+
+
+class BlockMultiEngine:
+    """The block variant on row slabs, one host process over `ngpu` GPUs (lanczos_hip_block_multi_*); several slabs on ONE
+    GPU with loopback=True (copies and a summing kernel in place of the collectives)."""
+
+    def __init__(self, a: "CrsMatrix", max_steps: int, ngpu: int, loopback: bool = False, devices=None):
+        self._h = C.c_void_p(None)
+        self.n, self.max_steps = a.dimension, max_steps
+        opt = Options(C.sizeof(Options), -1, None, 0, 0, 0, 0, 0, 0, None)
+        devs = (C.c_int * len(devices))(*devices) if devices else None
+        _check(_hip.lanczos_hip_block_multi_create(C.byref(self._h), ngpu, devs, a.dimension, a.length,
+                                                   a.row_head_indexes.ctypes.data_as(_ip), a.column_index.ctypes.data_as(_ip),
+                                                   a.values.ctypes.data_as(_dp), max_steps, C.byref(opt),
+                                                   1 if loopback else 0), "lanczos_hip_block_multi_create")
+
+    def close(self):
+        if self._h:
+            _hip.lanczos_hip_block_multi_destroy(self._h)
+            self._h = C.c_void_p(None)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_start(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        assert x0.shape == (self.n, BLOCK_WIDTH)
+        _check(_hip.lanczos_hip_block_multi_set_start(self._h, x0.ctypes.data_as(_dp)), "lanczos_hip_block_multi_set_start")
+
+    def set_start_seed(self, seed: int):
+        _check(_hip.lanczos_hip_block_multi_set_start_seed(self._h, seed), "lanczos_hip_block_multi_set_start_seed")
+
+    def run(self, steps: int):
+        _check(_hip.lanczos_hip_block_multi_run(self._h, steps), "lanczos_hip_block_multi_run")
+
+    @property
+    def steps(self) -> int:
+        return _hip.lanczos_hip_block_multi_steps(self._h)
+
+    @property
+    def slabs(self) -> int:
+        return _hip.lanczos_hip_block_multi_slabs(self._h)
+
+    def tmatrix(self, steps: int = None):
+        steps = self.steps if steps is None else steps
+        a = np.zeros((steps, BLOCK_WIDTH, BLOCK_WIDTH))
+        b = np.zeros((steps, BLOCK_WIDTH, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_multi_tmatrix(self._h, steps, a.ctypes.data_as(_dp), b.ctypes.data_as(_dp)),
+               "lanczos_hip_block_multi_tmatrix")
+        return a, b
+
+    def ritz(self, nth: int, steps: int = None) -> np.ndarray:
+        steps = self.steps if steps is None else steps
+        out = np.zeros(nth)
+        _check(_hip.lanczos_hip_block_multi_ritz(self._h, steps, nth, out.ctypes.data_as(_dp)), "lanczos_hip_block_multi_ritz")
+        return out
+
+    def get_block(self, t: int) -> np.ndarray:
+        out = np.zeros((self.n, BLOCK_WIDTH))
+        _check(_hip.lanczos_hip_block_multi_get_block(self._h, t, out.ctypes.data_as(_dp)), "lanczos_hip_block_multi_get_block")
+        return out
 
 
 class OmegaTracker:

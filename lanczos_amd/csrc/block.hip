@@ -273,26 +273,31 @@ struct BlockEngine {
     // slot t <- orthonormal basis of its columns; Bout (optional) = the factor: old = new * Bout
     // have_gram: d_small already holds W^T W of the block (left by the update that produced it)
     int cholqr2(int t, double *Bout, bool have_gram) {
-        double *G = d_small, *Rinv = d_small + 256, *R1 = d_small + 512, *R2 = d_small + 768;
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 0 && !have_gram)
-                if (int rc = gram(t, t + 1, slot(t), G)) return rc;
-            {
-                Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * 3);
-                hipLaunchKernelGGL(k_chol16, dim3(1), dim3(kThreads), 0, stream(), (const double *)G, Rinv,
-                                   pass == 0 ? R1 : R2, pass == 0 ? (const double *)nullptr : (const double *)R1,
-                                   pass == 0 ? (double *)nullptr : Bout, d_status, t + 1);
-            }
-            {
-                Scope ps(this, LANCZOS_HIP_BK_SCALE, 2.0 * 8.0 * kW * (double)n);
-                // the first scaling leaves the Gram matrix of its result for the second factorisation
-                hipLaunchKernelGGL(k_bscale16, dim3(groups_update), dim3(kThreads), 0, stream(), slot(t), n_pad,
-                                   (const double *)Rinv, pass == 0 ? d_hpart : (double *)nullptr);
-            }
-            if (pass == 0) reduce_own_gram(G);
-        }
+        if (!have_gram)
+            if (int rc = gram(t, t + 1, slot(t), d_small)) return rc;
+        for (int pass = 0; pass < 2; ++pass) chol_pass(pass, t, Bout);
         HIP_TRY(hipGetLastError());
         return 0;
+    }
+
+    // One of the two passes of cholqr2 on slot t, from the Gram matrix in d_small (of the whole block: summed over the
+    // slabs when the rows are partitioned): factorise, scale this engine's rows; the first pass leaves the Gram
+    // matrix of ITS rows' result in d_small for the second.
+    void chol_pass(int pass, int t, double *Bout) {
+        double *G = d_small, *Rinv = d_small + 256, *R1 = d_small + 512, *R2 = d_small + 768;
+        {
+            Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * 3);
+            hipLaunchKernelGGL(k_chol16, dim3(1), dim3(kThreads), 0, stream(), (const double *)G, Rinv,
+                               pass == 0 ? R1 : R2, pass == 0 ? (const double *)nullptr : (const double *)R1,
+                               pass == 0 ? (double *)nullptr : Bout, d_status, t + 1);
+        }
+        {
+            Scope ps(this, LANCZOS_HIP_BK_SCALE, 2.0 * 8.0 * kW * (double)n);
+            // the first scaling leaves the Gram matrix of its result for the second factorisation
+            hipLaunchKernelGGL(k_bscale16, dim3(groups_update), dim3(kThreads), 0, stream(), slot(t), n_pad,
+                               (const double *)Rinv, pass == 0 ? d_hpart : (double *)nullptr);
+        }
+        if (pass == 0) reduce_own_gram(G);
     }
 
     int set_start(const double *x0_host) {
@@ -349,6 +354,220 @@ struct BlockEngine {
 };
 
 BlockEngine *B(lanczos_hip_block *b) { return reinterpret_cast<BlockEngine *>(b); }
+
+// The block variant on row slabs, driven by ONE host process (the reference has neither a block form nor several
+// GPUs; what this must agree with is the one-GPU block engine).  Slab p holds rows [bounds[p], bounds[p+1]) of A with
+// its columns renumbered into a gathered table of X (slab q's rows at q * pad), the same rows of every basis block,
+// and its own copy of the small matrices.  Per block step: the slabs' rows of Q_j are gathered into every table
+// (all-gather of n x 16 doubles), then the step of the one-GPU engine with the 16 x 16 (x blocks) matrices summed over
+// the slabs wherever that engine sums over its rows: H = Q^T W twice, the Gram matrix of the new block twice.
+struct BlockMulti {
+    int P = 0;
+    bool loopback = false;
+    int64_t n = 0, pad = 0;
+    int max_steps = 0, steps = 0;
+    bool started = false;
+    std::vector<int> dev;
+    std::vector<int64_t> bounds;
+    std::vector<hipStream_t> stream;
+    std::vector<BlockEngine *> eng;
+    std::vector<double *> xtab;     // [P * pad][16] on every slab's device
+    std::vector<double *> bufH, bufG;
+    lz::SlabComm *comm = nullptr;
+
+    ~BlockMulti() {
+        for (size_t p = 0; p < eng.size(); ++p) {
+            if (p < dev.size()) (void)hipSetDevice(dev[p]);
+            delete eng[p];
+            if (p < xtab.size()) (void)hipFree(xtab[p]);
+        }
+        lz::slab_comm_destroy(comm);
+        for (size_t p = 0; p < stream.size(); ++p)
+            if (stream[p] && (!loopback || p == 0)) {
+                (void)hipSetDevice(dev[p]);
+                (void)hipStreamDestroy(stream[p]);
+            }
+    }
+    int use(int p) const {
+        if (hipSetDevice(dev[(size_t)p]) != hipSuccess) return lz::fail("hipSetDevice(%d) failed", dev[(size_t)p]);
+        return 0;
+    }
+    int reduce(std::vector<double *> &bufs, size_t count) { return lz::slab_all_reduce(comm, bufs.data(), count, stream.data()); }
+
+    int build(int ngpu, const int *devices, int64_t n_, int64_t nnz, const int64_t *rp, const int64_t *ci, const double *va,
+              int max_steps_, const lanczos_hip_options &opt_in, int flags) {
+        P = ngpu;
+        loopback = (flags & LANCZOS_HIP_MULTI_LOOPBACK) != 0;
+        n = n_;
+        max_steps = max_steps_;
+        int ndev = 0;
+        HIP_TRY(hipGetDeviceCount(&ndev));
+        dev.resize((size_t)P);
+        for (int p = 0; p < P; ++p) {
+            dev[(size_t)p] = loopback ? (devices ? devices[0] : (opt_in.device >= 0 ? opt_in.device : 0)) : (devices ? devices[p] : p);
+            if (dev[(size_t)p] < 0 || dev[(size_t)p] >= ndev)
+                return lz::fail("lanczos_hip_block_multi_create: device %d of %d visible (slab %d)", dev[(size_t)p], ndev, p);
+        }
+        bounds.resize((size_t)P + 1);
+        for (int p = 0; p <= P; ++p) bounds[(size_t)p] = (int64_t)(((__int128)p * n) / P);
+        for (int p = 0; p < P; ++p) {
+            if (bounds[(size_t)p + 1] - bounds[(size_t)p] < kW)
+                return lz::fail("lanczos_hip_block_multi_create: slab %d would hold fewer rows than the block width", p);
+            pad = std::max(pad, bounds[(size_t)p + 1] - bounds[(size_t)p]);
+        }
+        pad = (pad + 127) / 128 * 128;
+        if ((int64_t)P * pad > (int64_t)INT32_MAX) return lz::fail("lanczos_hip_block_multi_create: gathered table too long");
+        for (int64_t j = 0; j < nnz; ++j)
+            if (ci[j] < 0 || ci[j] >= n) return lz::fail("lanczos_hip_block_multi_create: column index out of range [0, %lld)", (long long)n);
+        stream.assign((size_t)P, nullptr);
+        eng.assign((size_t)P, nullptr);
+        xtab.assign((size_t)P, nullptr);
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            if (loopback && p > 0) stream[(size_t)p] = stream[0];
+            else HIP_TRY(hipStreamCreateWithFlags(&stream[(size_t)p], hipStreamNonBlocking));
+        }
+        if (int rc = lz::slab_comm_create(&comm, P, dev.data(), loopback)) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            const int64_t r0 = bounds[(size_t)p], r1 = bounds[(size_t)p + 1], nl = r1 - r0;
+            const int64_t e0 = rp[r0], cnt = rp[r1] - e0;
+            std::vector<int64_t> head((size_t)nl + 1), cols((size_t)std::max<int64_t>(cnt, 1));
+            for (int64_t i = 0; i <= nl; ++i) head[(size_t)i] = rp[r0 + i] - e0;
+            for (int64_t j = 0; j < cnt; ++j) {
+                const int64_t c = ci[e0 + j];
+                const int q = (int)(std::upper_bound(bounds.begin(), bounds.end(), c) - bounds.begin()) - 1;
+                cols[(size_t)j] = (int64_t)q * pad + (c - bounds[(size_t)q]);
+            }
+            const size_t tab_bytes = sizeof(double) * kW * (size_t)P * (size_t)pad;
+            HIP_TRY(hipMalloc(&xtab[(size_t)p], tab_bytes));
+            HIP_TRY(hipMemsetAsync(xtab[(size_t)p], 0, tab_bytes, stream[(size_t)p]));
+            lanczos_hip_options o = opt_in;
+            o.struct_size = sizeof o;
+            o.device = dev[(size_t)p];
+            o.stream = stream[(size_t)p];
+            o.reorth = LANCZOS_HIP_REORTH_NONE;      // the base engine only holds the slab's matrix
+            o.spmv_kernel = LANCZOS_HIP_SPMV_VECTOR;
+            o.profile = 0;
+            o.n_global = n;
+            o.row_begin = r0;
+            o.n_ext = (int64_t)P * pad;
+            o.x_ext = xtab[(size_t)p];               // never read as a vector: the table holds 16 doubles per column
+            o.basis = nullptr;
+            lz::Engine *base = nullptr;
+            if (int rc = lz::Engine::create(&base, nl, cnt, head.data(), cols.data(), va + e0, 2, &o)) return rc;
+            BlockEngine *b = new BlockEngine();
+            b->base = base;
+            eng[(size_t)p] = b;
+            if (int rc = b->alloc(max_steps, false)) return rc;
+        }
+        bufH.resize((size_t)P);
+        bufG.resize((size_t)P);
+        for (int p = 0; p < P; ++p) {
+            bufH[(size_t)p] = eng[(size_t)p]->d_H;
+            bufG[(size_t)p] = eng[(size_t)p]->d_small;
+        }
+        return 0;
+    }
+
+    // Q_0 <- an orthonormal basis of x0's columns (n x 16 row-major on the host)
+    int set_start(const double *x0) {
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            BlockEngine *b = eng[(size_t)p];
+            HIP_TRY(hipMemsetAsync(b->d_Q, 0, sizeof(double) * (size_t)b->blk_stride * (size_t)(max_steps + 1), b->stream()));
+            HIP_TRY(hipMemcpyAsync(b->slot(0), x0 + (size_t)bounds[(size_t)p] * kW, sizeof(double) * (size_t)b->n * kW,
+                                   hipMemcpyHostToDevice, b->stream()));
+            HIP_TRY(hipMemsetAsync(b->d_status, 0, sizeof(int), b->stream()));
+            if (int rc = b->gram(0, 1, b->slot(0), b->d_small)) return rc;
+        }
+        if (int rc = orthonormalise(0, (const size_t *)nullptr)) return rc;
+        steps = 0;
+        started = true;
+        return sync_and_check();
+    }
+
+    // the two passes of the one-GPU engine's cholqr2 with the Gram matrices (the slabs' parts are in d_small) summed over the slabs
+    int orthonormalise(int t, const size_t *tb_offset) {
+        for (int pass = 0; pass < 2; ++pass) {
+            if (int rc = reduce(bufG, 256)) return rc;
+            for (int p = 0; p < P; ++p) {
+                if (int rc = use(p)) return rc;
+                BlockEngine *b = eng[(size_t)p];
+                b->chol_pass(pass, t, tb_offset ? b->d_TB + *tb_offset : nullptr);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    int sync_and_check() {
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            HIP_TRY(hipStreamSynchronize(stream[(size_t)p]));
+            if (int rc = eng[(size_t)p]->check_status()) return rc;
+        }
+        return 0;
+    }
+
+    int step() {
+        if (!started) return lz::fail("lanczos_hip_block_multi: no start block set");
+        if (steps >= max_steps) return lz::fail("lanczos_hip_block_multi: basis full (%d block steps)", steps);
+        const int j = steps;
+        const int ta = std::max(j - 1, 0);
+        // every slab's rows of Q_j into its place of its own table, then into everybody's
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            BlockEngine *b = eng[(size_t)p];
+            HIP_TRY(hipMemcpyAsync(xtab[(size_t)p] + (size_t)p * (size_t)pad * kW, b->slot(j), sizeof(double) * (size_t)b->n * kW,
+                                   hipMemcpyDeviceToDevice, b->stream()));
+        }
+        if (int rc = lz::slab_all_gather(comm, xtab.data(), (size_t)pad * kW, (size_t)pad * kW, stream.data())) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            BlockEngine *b = eng[(size_t)p];
+            if (int rc = b->spmm(xtab[(size_t)p], b->slot(j + 1))) return rc;
+            if (int rc = b->gram(ta, j + 1, b->slot(j + 1), b->d_H)) return rc;
+        }
+        if (int rc = reduce(bufH, (size_t)(j + 1 - ta) * 256)) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            BlockEngine *b = eng[(size_t)p];
+            hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, b->stream(), (const double *)(b->d_H + (j - ta) * 256),
+                               b->d_TA + (size_t)j * 256);
+            if (int rc = b->update(ta, j + 1, b->slot(j + 1), b->d_H, nullptr)) return rc;
+            if (int rc = b->gram(0, j + 1, b->slot(j + 1), b->d_H)) return rc;
+        }
+        if (int rc = reduce(bufH, (size_t)(j + 1) * 256)) return rc;
+        for (int p = 0; p < P; ++p) {
+            if (int rc = use(p)) return rc;
+            BlockEngine *b = eng[(size_t)p];
+            if (int rc = b->update(0, j + 1, b->slot(j + 1), b->d_H, b->d_small)) return rc;
+        }
+        const size_t tb = (size_t)j * 256;
+        if (int rc = orthonormalise(j + 1, &tb)) return rc;
+        steps += 1;
+        return 0;
+    }
+
+    int run(int count) {
+        for (int s = 0; s < count; ++s)
+            if (int rc = step()) return rc;
+        return sync_and_check();
+    }
+};
+
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() {
+        if (hipGetDevice(&dev) != hipSuccess) dev = -1;
+    }
+    ~DeviceGuard() {
+        if (dev >= 0) (void)hipSetDevice(dev);
+    }
+};
+
+BlockMulti *BM(lanczos_hip_block_multi *m) { return reinterpret_cast<BlockMulti *>(m); }
 
 }  // namespace
 
@@ -541,6 +760,110 @@ void lanczos_hip_block_profile_reset(lanczos_hip_block *bh) {
         b->prof_bytes[c] = 0;
         b->prof_launches[c] = 0;
     }
+}
+
+// ---- the block variant on row slabs -----------------------------------------------------------------------------
+
+int lanczos_hip_block_multi_create(lanczos_hip_block_multi **out, int ngpu, const int *devices, int64_t n, int64_t nnz,
+                                   const int64_t *row_head_indexes, const int64_t *column_index, const double *values,
+                                   int max_steps, const lanczos_hip_options *opt_in, int flags) {
+    return lz::guarded("lanczos_hip_block_multi_create", [&]() -> int {
+    if (!out) return lz::fail("lanczos_hip_block_multi_create: NULL handle");
+    *out = nullptr;
+    if (ngpu < 1 || ngpu > 64) return lz::fail("lanczos_hip_block_multi_create: ngpu=%d", ngpu);
+    if (max_steps < 1) return lz::fail("lanczos_hip_block_multi_create: max_steps must be >= 1");
+    if (n <= 0 || nnz < 0 || !row_head_indexes || (nnz > 0 && (!column_index || !values)) || row_head_indexes[0] != 0 ||
+        row_head_indexes[n] != nnz)
+        return lz::fail("lanczos_hip_block_multi_create: bad matrix");
+    lanczos_hip_options opt;
+    memset(&opt, 0, sizeof opt);
+    opt.device = -1;
+    if (opt_in) memcpy(&opt, opt_in, std::min(sizeof opt, opt_in->struct_size));
+    if (opt.x_ext || opt.basis) return lz::fail("lanczos_hip_block_multi_create: pass the whole matrix; the slabs are cut here");
+    DeviceGuard guard;
+    BlockMulti *m = new BlockMulti();
+    if (int rc = m->build(ngpu, devices, n, nnz, row_head_indexes, column_index, values, max_steps, opt, flags)) {
+        delete m;
+        return rc;
+    }
+    *out = reinterpret_cast<lanczos_hip_block_multi *>(m);
+    return 0;
+    });
+}
+
+void lanczos_hip_block_multi_destroy(lanczos_hip_block_multi *m) {
+    DeviceGuard guard;
+    delete BM(m);
+}
+
+int lanczos_hip_block_multi_set_start(lanczos_hip_block_multi *m, const double *x0_host) {
+    return lz::guarded("lanczos_hip_block_multi_set_start", [&]() -> int {
+    if (!m || !x0_host) return lz::fail("lanczos_hip_block_multi_set_start: NULL argument");
+    DeviceGuard guard;
+    return BM(m)->set_start(x0_host);
+    });
+}
+
+int lanczos_hip_block_multi_set_start_seed(lanczos_hip_block_multi *m, uint64_t seed) {
+    return lz::guarded("lanczos_hip_block_multi_set_start_seed", [&]() -> int {
+    if (!m) return lz::fail("lanczos_hip_block_multi_set_start_seed: NULL handle");
+    std::vector<double> x((size_t)BM(m)->n * kW);
+    lanczos_hip_gaussian_fill(seed, 0, (int64_t)x.size(), x.data());
+    DeviceGuard guard;
+    return BM(m)->set_start(x.data());
+    });
+}
+
+int lanczos_hip_block_multi_run(lanczos_hip_block_multi *m, int steps) {
+    return lz::guarded("lanczos_hip_block_multi_run", [&]() -> int {
+    if (!m || steps < 0) return lz::fail("lanczos_hip_block_multi_run: bad argument");
+    DeviceGuard guard;
+    return BM(m)->run(steps);
+    });
+}
+
+int lanczos_hip_block_multi_steps(const lanczos_hip_block_multi *m) {
+    return m ? reinterpret_cast<const BlockMulti *>(m)->steps : 0;
+}
+
+int lanczos_hip_block_multi_slabs(const lanczos_hip_block_multi *m) {
+    return m ? reinterpret_cast<const BlockMulti *>(m)->P : 0;
+}
+
+int lanczos_hip_block_multi_tmatrix(lanczos_hip_block_multi *mh, int steps, double *a_out, double *b_out) {
+    return lz::guarded("lanczos_hip_block_multi_tmatrix", [&]() -> int {
+    BlockMulti *m = BM(mh);
+    if (!m || steps < 0 || steps > m->steps) return lz::fail("lanczos_hip_block_multi_tmatrix: bad argument");
+    DeviceGuard guard;
+    if (int rc = m->sync_and_check()) return rc;
+    // every slab holds the same T: slab 0's copy
+    m->eng[0]->steps = m->steps;
+    return lanczos_hip_block_tmatrix(reinterpret_cast<lanczos_hip_block *>(m->eng[0]), steps, a_out, b_out);
+    });
+}
+
+int lanczos_hip_block_multi_ritz(lanczos_hip_block_multi *mh, int steps, int nth, double *eig_out) {
+    return lz::guarded("lanczos_hip_block_multi_ritz", [&]() -> int {
+    BlockMulti *m = BM(mh);
+    if (!m || !eig_out || nth < 1 || steps < 1 || steps > m->steps) return lz::fail("lanczos_hip_block_multi_ritz: bad argument");
+    DeviceGuard guard;
+    if (int rc = m->sync_and_check()) return rc;
+    m->eng[0]->steps = m->steps;
+    return lanczos_hip_block_ritz(reinterpret_cast<lanczos_hip_block *>(m->eng[0]), steps, nth, eig_out);
+    });
+}
+
+int lanczos_hip_block_multi_get_block(lanczos_hip_block_multi *mh, int t, double *out_host) {
+    return lz::guarded("lanczos_hip_block_multi_get_block", [&]() -> int {
+    BlockMulti *m = BM(mh);
+    if (!m || !out_host || t < 0 || t > m->max_steps) return lz::fail("lanczos_hip_block_multi_get_block: bad argument");
+    DeviceGuard guard;
+    for (int p = 0; p < m->P; ++p)
+        if (int rc = lanczos_hip_block_get_block(reinterpret_cast<lanczos_hip_block *>(m->eng[(size_t)p]), t,
+                                                 out_host + (size_t)m->bounds[(size_t)p] * kW))
+            return rc;
+    return 0;
+    });
 }
 
 }  // extern "C"

@@ -228,4 +228,17 @@ struct Engine {
     void harvest_completed();
 };
 
+// Collectives over the row slabs that ONE host process drives (multi.hip): RCCL communicators over the slabs' devices
+// (ncclCommInitAll, calls grouped over the devices), or, with every slab on one device and one stream, copies and a
+// summing kernel in their place.  Shared by the single-vector and the block form of the row-partitioned iteration.
+struct SlabComm;
+int slab_comm_create(SlabComm **out, int slabs, const int *devices, bool loopback);
+void slab_comm_destroy(SlabComm *c);
+// bufs[p][0..count) <- sum over the slabs, in place, ordered behind what streams[p] holds; slabs added in ascending order
+// by the loopback form
+int slab_all_reduce(SlabComm *c, double *const *bufs, size_t count, const hipStream_t *streams);
+// tables[p] + q * stride is the place of slab q's piece (count <= stride doubles) in slab p's table; slab p's own piece is
+// there already, the others arrive
+int slab_all_gather(SlabComm *c, double *const *tables, size_t stride, size_t count, const hipStream_t *streams);
+
 }  // namespace lz

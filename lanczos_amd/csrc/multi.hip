@@ -135,6 +135,102 @@ __global__ void __launch_bounds__(256) k_sum_slabs(double *const *__restrict__ b
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// the transport on its own (engine.h): what the block variant's row slabs use
+// ---------------------------------------------------------------------------
+namespace {
+constexpr int kMaxSlabs = 64;
+struct SlabPtrs { double *p[kMaxSlabs]; };
+__global__ void __launch_bounds__(256) k_sum_slab_args(SlabPtrs bufs, int slabs, size_t count) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    double s = 0.0;
+    for (int q = 0; q < slabs; ++q) s += bufs.p[q][i];
+    for (int q = 0; q < slabs; ++q) bufs.p[q][i] = s;
+}
+}  // namespace
+
+namespace lz {
+
+struct SlabComm {
+    int P = 0;
+    bool loopback = false;
+    std::vector<int> dev;
+    std::vector<ncclComm_t> comm;
+};
+
+int slab_comm_create(SlabComm **out, int slabs, const int *devices, bool loopback) {
+    *out = nullptr;
+    if (slabs < 1 || slabs > kMaxSlabs || !devices) return fail("slab transport: %d slabs", slabs);
+    SlabComm *c = new SlabComm();
+    c->P = slabs;
+    c->loopback = loopback;
+    c->dev.assign(devices, devices + slabs);
+    if (!loopback) {
+        if (!rccl()) {
+            delete c;
+            return fail("slab transport: librccl.so could not be opened (several GPUs need it; one GPU can rehearse with the "
+                        "loopback transport)");
+        }
+        c->comm.assign((size_t)slabs, nullptr);
+        const ncclResult_t st = rccl()->CommInitAll(c->comm.data(), slabs, c->dev.data());
+        if (st != ncclSuccess) {
+            c->comm.clear();
+            delete c;
+            return fail("slab transport: ncclCommInitAll over %d devices: %s", slabs, rccl()->GetErrorString(st));
+        }
+    }
+    *out = c;
+    return 0;
+}
+
+void slab_comm_destroy(SlabComm *c) {
+    if (!c) return;
+    for (ncclComm_t x : c->comm)
+        if (x && rccl()) (void)rccl()->CommDestroy(x);
+    delete c;
+}
+
+int slab_all_reduce(SlabComm *c, double *const *bufs, size_t count, const hipStream_t *streams) {
+    if (count == 0) return 0;
+    if (c->loopback) {
+        if (c->P == 1) return 0;
+        SlabPtrs a;
+        for (int p = 0; p < c->P; ++p) a.p[p] = bufs[p];
+        hipLaunchKernelGGL(k_sum_slab_args, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, streams[0], a, c->P, count);
+        M_HIP(hipGetLastError());
+        return 0;
+    }
+    M_RCCL(rccl()->GroupStart());
+    for (int p = 0; p < c->P; ++p) {
+        M_HIP(hipSetDevice(c->dev[(size_t)p]));
+        M_RCCL(rccl()->AllReduce(bufs[p], bufs[p], count, ncclDouble, ncclSum, c->comm[(size_t)p], streams[p]));
+    }
+    M_RCCL(rccl()->GroupEnd());
+    return 0;
+}
+
+int slab_all_gather(SlabComm *c, double *const *tables, size_t stride, size_t count, const hipStream_t *streams) {
+    if (count > stride) return fail("slab transport: piece of %zu doubles in places of %zu", count, stride);
+    if (c->loopback) {
+        for (int p = 0; p < c->P; ++p)
+            for (int q = 0; q < c->P; ++q)
+                if (q != p)
+                    M_HIP(hipMemcpyAsync(tables[p] + (size_t)q * stride, tables[q] + (size_t)q * stride, sizeof(double) * count,
+                                         hipMemcpyDeviceToDevice, streams[0]));
+        return 0;
+    }
+    M_RCCL(rccl()->GroupStart());
+    for (int p = 0; p < c->P; ++p) {
+        M_HIP(hipSetDevice(c->dev[(size_t)p]));
+        M_RCCL(rccl()->AllGather(tables[p] + (size_t)p * stride, tables[p], stride, ncclDouble, c->comm[(size_t)p], streams[p]));
+    }
+    M_RCCL(rccl()->GroupEnd());
+    return 0;
+}
+
+}  // namespace lz
+
 struct lanczos_hip_multi {
     int P = 0;
     bool loopback = false;

@@ -58,8 +58,10 @@ k_hub_keys(const int *__restrict__ rows, int64_t H, const RP *__restrict__ rp, c
         const int64_t q0 = (int64_t)hoff[h];
         for (int64_t j = threadIdx.x; j < len; j += kT) {
             const int c = col[e0 + j];
-            const int64_t deg = (int64_t)rp[c + 1] - (int64_t)rp[c];
-            const uint32_t vc = (uint32_t)col_class(c) + (deg < degree_floor ? 8u : 0u);
+            // a column's popularity is its row's length (symmetric matrices); never looked up without the split: the
+            // columns of a row slab are places in a gathered table, not rows of this matrix
+            uint32_t vc = (uint32_t)col_class(c);
+            if (degree_floor > 0 && (int64_t)rp[c + 1] - (int64_t)rp[c] < degree_floor) vc += 8u;
             keys[q0 + j] = (vc << hbits) | (uint32_t)h;
             idx[q0 + j] = (uint32_t)(e0 + j);
         }

@@ -202,6 +202,20 @@ static void check_block(const Mat_Crs *a, const char *what, int steps) {
     }
     CHECK(worst <= 1e-12 * scale, "%s: block product differs from the host product by %g of %g", what, worst, scale);
     printf("api_check: %s: block variant, lowest Ritz value %.12g after %d block steps; product error %.1e\n", what, eig[0], steps, worst / fmax(scale, 1e-300));
+    /* the same run with the rows cut into three slabs on this GPU */
+    lanczos_hip_block_multi *bm = NULL;
+    double eig3[4];
+    CHECK(lanczos_hip_block_multi_create(&bm, 3, NULL, n, (int64_t)a->length, a->row_head_indexes, a->column_index, a->values, steps, &o,
+                                         LANCZOS_HIP_MULTI_LOOPBACK) == 0, "%s: block_multi_create", what);
+    if (bm) {
+        CHECK(lanczos_hip_block_multi_set_start_seed(bm, 3) == 0 && lanczos_hip_block_multi_run(bm, steps) == 0, "%s: block_multi run", what);
+        CHECK(lanczos_hip_block_multi_ritz(bm, steps, 4, eig3) == 0, "%s: block_multi_ritz", what);
+        double w3 = 0.0;
+        for (int i = 0; i < 4; ++i) w3 = fmax(w3, rel(eig3[i], eig[i]));
+        CHECK(w3 < 1e-10, "%s: three slabs differ from one engine by %g", what, w3);
+        printf("api_check: %s: block variant on 3 slabs within %.1e of one engine\n", what, w3);
+        lanczos_hip_block_multi_destroy(bm);
+    }
     free(q0);
     free(q1);
     free(x);

@@ -214,3 +214,70 @@ def test_block_limits(gpu):
     with la.BlockEngine(a, 2) as e:
         with pytest.raises(la.LanczosHipError, match="no start block"):
             e.run(1)
+
+
+@pytest.mark.parametrize("slabs", [2, 3, 5])
+def test_block_variant_on_row_slabs_matches_one_engine(gpu, slabs, monkeypatch):
+    """The block variant with its rows cut into slabs (one host process, every slab on this GPU through the loopback
+    transport): per block step an all-gather of Q_j into every slab's table and four reductions of 16 x 16 matrices
+    over the slabs.  Against the one-GPU block engine on the same start block: the blocks of T, the Ritz values and
+    the basis blocks agree to rounding (the sums over the rows are taken slab by slab); against the numpy model as the
+    one-GPU engine is.  A 3-D Laplacian, a random symmetric matrix, and a power-law graph with the regrouped sparse
+    product forced on in every slab."""
+    from matrices import rmat_laplacian
+    from test_gpu_parity import crs_from_scipy
+    cases = [("lap3d", la.synth_laplacian(3, 22), 7, {}), ("random", la.synth_random_symmetric(30011, 6, 5), 5, {}),
+             ("rmat", crs_from_scipy(-rmat_laplacian(13)), 6, {"LANCZOS_HIP_SPMM_HUB": "2"})]
+    for name, a, steps, env in cases:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        x0 = start_block(a.dimension, 3)
+        with la.BlockEngine(a, steps) as e:
+            e.set_start(x0)
+            e.run(steps)
+            ta, tb = e.tmatrix()
+            ritz = e.ritz(4)
+            q = [e.get_block(t) for t in (0, 1, steps)]
+        with la.BlockMultiEngine(a, steps, slabs, loopback=True) as m:
+            assert m.slabs == slabs
+            m.set_start(x0)
+            m.run(steps - 2)
+            m.run(2)                                  # a run goes on where the last one stopped
+            assert m.steps == steps
+            ma, mb = m.tmatrix()
+            mritz = m.ritz(4)
+            mq = [m.get_block(t) for t in (0, 1, steps)]
+        scale = np.abs(ta).max()
+        assert np.abs(ma - ta).max() < 1e-10 * scale and np.abs(mb - tb).max() < 1e-10 * scale, name
+        assert rel_err(mritz, ritz) < 1e-10, name
+        for got, want in zip(mq, q):
+            assert np.abs(got - want).max() < 1e-8, name
+        # the basis the slabs hold is orthonormal
+        assert np.abs(mq[2].T @ mq[2] - np.eye(16)).max() < 1e-12 and np.abs(mq[0].T @ mq[2]).max() < 1e-12, name
+        for k in env:
+            monkeypatch.delenv(k)
+
+
+def test_block_variant_on_row_slabs_by_seed_and_limits(gpu):
+    """The start block drawn by seed is the one-GPU engine's (a function of seed and global row); slabs of fewer rows
+    than the block width, a full basis and a missing start block are refused."""
+    a = la.synth_laplacian(2, 70)
+    with la.BlockEngine(a, 4) as e:
+        e.set_start_seed(9)
+        e.run(4)
+        want = e.ritz(3)
+    with la.BlockMultiEngine(a, 4, 4, loopback=True) as m:
+        with pytest.raises(la.LanczosHipError, match="no start block"):
+            m.run(1)
+        m.set_start_seed(9)
+        m.run(4)
+        assert rel_err(m.ritz(3), want) < 1e-10
+        with pytest.raises(la.LanczosHipError, match="basis full"):
+            m.run(1)
+    with pytest.raises(la.LanczosHipError, match="fewer rows than the block width"):
+        la.BlockMultiEngine(la.synth_laplacian(1, 40), 2, 3, loopback=True)
+    # one slab through librccl (ncclCommInitAll over one device, in-place all-gather, all-reduce): the calls a node makes
+    with la.BlockMultiEngine(a, 4, 1) as m:
+        m.set_start_seed(9)
+        m.run(4)
+        assert rel_err(m.ritz(3), want) < 1e-12
