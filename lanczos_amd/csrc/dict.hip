@@ -442,7 +442,7 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
                    int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
                    const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
-                   int64_t dot_lo, int64_t dot_hi) {
+                   int64_t dot_lo, int64_t dot_hi, int cache_patterns) {
     constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
     static_assert(ROWS == 2, "two rows per thread");
     extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
@@ -495,6 +495,11 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
         dict_d2 W[WPT / 2];
         uint32_t pq;
         int32_t head[ROWS];   // where this thread's rows of the next step begin in the value array
+        // the pattern this wavefront's rows shared last (its place in the tables), its values and window offsets
+        int c_base = -1;
+        double c_val[8];
+        int c_idx[3][8];
+        const bool use_cache = !CRS_VALUES && stride <= 8 && cache_patterns;
         // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
         // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
         const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
@@ -573,9 +578,33 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
                     }
                 }
             } else {
-                for (int j = 0; j < stride; ++j) {
+                // Away from the grid's faces every row of a wavefront has the same pattern, and it is the pattern the
+                // wavefront met one plane earlier: its values and window offsets then stay in registers (c_val, c_idx)
+                // and a row costs its seven reads of x from LDS, not those plus fourteen reads of the tables.  Same
+                // products in the same order: the entries past a pattern's end multiply -0.0 by the zeros' region here
+                // as in the tables.
+                const int p0 = __builtin_amdgcn_readfirstlane(base[0]);
+                if (use_cache && __all(base[0] == p0 && base[1] == p0)) {
+                    if (p0 != c_base) {
+                        c_base = p0;
 #pragma unroll
-                    for (int u = 0; u < ROWS; ++u) sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + idx[base[u] + j]];
+                        for (int j = 0; j < 8; ++j) {
+                            const bool in = j < stride;
+                            c_val[j] = in ? s_val[p0 + j] : -0.0;
+#pragma unroll
+                            for (int rot = 0; rot < 3; ++rot) c_idx[rot][j] = in ? s_idx[rot * tab + p0 + j] : 3 * wlen;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                        for (int u = 0; u < ROWS; ++u) sum[u] += c_val[j] * win[u * BLOCK + tid + c_idx[ROT][j]];
+                    }
+                } else {
+                    for (int j = 0; j < stride; ++j) {
+#pragma unroll
+                        for (int u = 0; u < ROWS; ++u) sum[u] += s_val[base[u] + j] * win[u * BLOCK + tid + idx[base[u] + j]];
+                    }
                 }
             }
 #pragma unroll
@@ -885,7 +914,7 @@ using DictAheadKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, i
                                  int64_t);
 using DictPlanesKernel = void (*)(int64_t, int64_t, int64_t, const int32_t *, const double *, const uint16_t *, int, int,
                                   int, const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
-                                  const double *, const double *, double *, double *, int64_t, int64_t);
+                                  const double *, const double *, double *, double *, int64_t, int64_t, int);
 
 // window doubles per thread (even: loaded in pairs) for a window of `wlen` doubles and `block` threads
 static int dict_window_per_thread(int wlen, int block) { return 2 * ((wlen / 2 + block - 1) / block); }
@@ -943,7 +972,7 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
                        (const double *)d_val, (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,
                        (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval, (int)dict_plane_a,
                        (int)dict_plane_b, (int)dict_plane_f, cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials,
-                       (int64_t)0, n);
+                       (int64_t)0, n, 0);
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;
@@ -964,6 +993,12 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
         const int w = dict_window_per_thread(wlen, kPlanesBlock);
+        // A wavefront whose 128 rows share one pattern keeps that pattern's values and offsets in registers.  The rows at
+        // the ends of a grid line have patterns of their own, so this pays when the lines are long (512^3: 6 of 8
+        // wavefronts, 0.549 -> 0.521 ms; 256^3: 2 of 4, 0.077 -> 0.078 ms): on from an in-plane reach of 384 rows.
+        // LANCZOS_HIP_DICT_CACHE=0 / 1 overrides (the results are the same bits).
+        const char *cache_env = getenv("LANCZOS_HIP_DICT_CACHE");
+        const int cache_patterns = cache_env && *cache_env ? atoi(cache_env) != 0 : dict_halo >= 384;
         const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, false>
                                         : w <= 6 ? k_spmv_dict_planes<6, false>
                                                  : k_spmv_dict_planes<10, false>;
@@ -978,7 +1013,7 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, nnz,
                            (const int32_t *)nullptr, (const double *)nullptr, pat, dict_patterns, dict_stride, dict_halo,
                            dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
-                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);
+                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi, cache_patterns);
     } else if (form == 1) {
         // loads one step ahead; 16-byte loads when no pair of doubles can straddle the start of x
         // (LANCZOS_HIP_DICT_WIDE=0: never); 512 threads, two rows per thread (LANCZOS_HIP_DICT_BLOCK=256: four)

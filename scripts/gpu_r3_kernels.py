@@ -112,10 +112,49 @@ def fuse_form(sizes):
     return out
 
 
+def dict_cache_form(sizes):
+    """The plane-walking dictionary SpMV with the wavefront's pattern kept in registers (LANCZOS_HIP_DICT_CACHE, read at
+    every launch) against the form that reads the tables for every row: same bits on several grids, then HIP-event time
+    per launch on the given grids, alternating."""
+    rng = np.random.default_rng(0)
+    out = {"bitwise": {}, "timing": {}}
+    for N in (20, 33, 64, 97):
+        a = la.synth_laplacian(3, N)
+        x = rng.standard_normal(a.dimension)
+        with la.Engine(a, 3, reorth="none", spmv="dict") as e:
+            os.environ["LANCZOS_HIP_DICT_CACHE"] = "0"
+            y0 = e.spmv(x)
+            os.environ["LANCZOS_HIP_DICT_CACHE"] = "1"
+            y1 = e.spmv(x)
+            name = e.spmv_name
+        out["bitwise"][f"lap3d-{N} {name}"] = bool(y0.tobytes() == y1.tobytes())
+        print(N, name, "bitwise equal:", y0.tobytes() == y1.tobytes(), flush=True)
+    for N in sizes:
+        a = la.synth_laplacian(3, N)
+        res = {}
+        with la.Engine(a, 4, reorth="none", spmv="dict", profile=True) as e:
+            for rnd in range(3):
+                for c in ("0", "1"):
+                    os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+                    e.set_start_seed(1)
+                    e.run(3)
+                    e.profile_reset()
+                    e.run(100)
+                    p = e.profile()
+                    res.setdefault(c, []).append(p["spmv"]["ms"] / 100)
+            bytes_ = p["spmv"]["bytes"] / 100
+            name = e.spmv_name
+        for c, v in res.items():
+            out["timing"][f"{N}^3 cache={c}"] = {"ms_per_spmv": v, "best_TBps": bytes_ / min(v) / 1e9}
+            print(f"{N}^3 {name} cache={c}: {[round(t, 4) for t in v]} ms per SpMV, best {bytes_ / min(v) / 1e9:.3f} TB/s", flush=True)
+    return out
+
+
 if __name__ == "__main__":
     what = sys.argv[1]
     sizes = [int(s) for s in sys.argv[2:]] or ([256] if what == "rows" else [256, 512])
-    res = rows_form(sizes) if what == "rows" else fuse_form(sizes) if what == "fuse" else recur_form(sizes)
+    res = (rows_form(sizes) if what == "rows" else fuse_form(sizes) if what == "fuse" else dict_cache_form(sizes) if what == "dictcache"
+           else recur_form(sizes))
     tag = os.environ.get("R3_TAG", what)
     os.makedirs("gpurun_out/r3k", exist_ok=True)
     json.dump(res, open(f"gpurun_out/r3k/{tag}.json", "w"), indent=1)
