@@ -435,14 +435,17 @@ static size_t dict_planes_lds_bytes(int halo, int patterns, int stride) {
 // per row and x is taken from the ring of windows just the same; the values are read from the CRS array where
 // they lie, through the row offsets (src/crs.c:155-178 reads values, column indices and row offsets: 16 bytes
 // per entry; this form 8 bytes per entry plus 6 per row).  Rows of up to eight entries; sums left to right.
-template <int WPT, bool CRS_VALUES>
+// CACHE (dictionary form only): 0 every row reads its pattern's values and window offsets from the LDS tables; 1 a
+// wavefront whose rows share one pattern keeps the values in registers; 2 the values and the offsets of the three ring
+// positions (40 registers more: two workgroups per CU where the other forms have three).
+template <int WPT, bool CRS_VALUES, int CACHE>
 __global__ void __launch_bounds__(kPlanesBlock)
 k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restrict__ rp, const double *__restrict__ val, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                    int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
                    const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
-                   int64_t dot_lo, int64_t dot_hi, int cache_patterns) {
+                   int64_t dot_lo, int64_t dot_hi) {
     constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
     static_assert(ROWS == 2, "two rows per thread");
     extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
@@ -495,11 +498,11 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
         dict_d2 W[WPT / 2];
         uint32_t pq;
         int32_t head[ROWS];   // where this thread's rows of the next step begin in the value array
-        // the pattern this wavefront's rows shared last (its place in the tables), its values and window offsets
+        // the pattern this wavefront's rows shared last (its place in the tables) and its values
         int c_base = -1;
-        double c_val[8];
-        int c_idx[3][8];
-        const bool use_cache = !CRS_VALUES && stride <= 8 && cache_patterns;
+        double c_val[CACHE ? 8 : 1];
+        int c_idx[CACHE == 2 ? 3 : 1][CACHE == 2 ? 8 : 1];
+        const bool use_cache = !CRS_VALUES && CACHE != 0 && stride <= 8;
         // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
         // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
         const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
@@ -584,21 +587,27 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
                 // products in the same order: the entries past a pattern's end multiply -0.0 by the zeros' region here
                 // as in the tables.
                 const int p0 = __builtin_amdgcn_readfirstlane(base[0]);
-                if (use_cache && __all(base[0] == p0 && base[1] == p0)) {
+                if (CACHE != 0 && use_cache && __all(base[0] == p0 && base[1] == p0)) {
                     if (p0 != c_base) {
                         c_base = p0;
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
                             const bool in = j < stride;
-                            c_val[j] = in ? s_val[p0 + j] : -0.0;
+                            if constexpr (CACHE != 0) c_val[j] = in ? s_val[p0 + j] : -0.0;
+                            if constexpr (CACHE == 2) {
 #pragma unroll
-                            for (int rot = 0; rot < 3; ++rot) c_idx[rot][j] = in ? s_idx[rot * tab + p0 + j] : 3 * wlen;
+                                for (int rot = 0; rot < 3; ++rot) c_idx[rot][j] = in ? s_idx[rot * tab + p0 + j] : 3 * wlen;
+                            }
                         }
                     }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
+                        int e;
+                        if constexpr (CACHE == 2) e = c_idx[ROT][j];
+                        else e = j < stride ? idx[p0 + j] : 3 * wlen;   // one address for all lanes: one bank, no conflict
+                        const double v = c_val[CACHE ? j : 0];
 #pragma unroll
-                        for (int u = 0; u < ROWS; ++u) sum[u] += c_val[j] * win[u * BLOCK + tid + c_idx[ROT][j]];
+                        for (int u = 0; u < ROWS; ++u) sum[u] += v * win[u * BLOCK + tid + e];
                     }
                 } else {
                     for (int j = 0; j < stride; ++j) {
@@ -914,7 +923,10 @@ using DictAheadKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, i
                                  int64_t);
 using DictPlanesKernel = void (*)(int64_t, int64_t, int64_t, const int32_t *, const double *, const uint16_t *, int, int,
                                   int, const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
-                                  const double *, const double *, double *, double *, int64_t, int64_t, int);
+                                  const double *, const double *, double *, double *, int64_t, int64_t);
+
+// which register form of the plane walk runs when LANCZOS_HIP_DICT_CACHE does not say (measured on 256^3 and 512^3)
+static int kDictCacheDefault(int halo) { return halo >= 384 ? 2 : 0; }
 
 // window doubles per thread (even: loaded in pairs) for a window of `wlen` doubles and `block` threads
 static int dict_window_per_thread(int wlen, int block) { return 2 * ((wlen / 2 + block - 1) / block); }
@@ -957,9 +969,9 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
     const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
     const size_t lds = pdict_lds_bytes(dict_halo, dict_patterns, dict_stride);
     const int w = dict_window_per_thread(wlen, kPlanesBlock);
-    const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, true>
-                                 : w <= 6 ? k_spmv_dict_planes<6, true>
-                                          : k_spmv_dict_planes<10, true>;
+    const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, true, 0>
+                                 : w <= 6 ? k_spmv_dict_planes<6, true, 0>
+                                          : k_spmv_dict_planes<10, true, 0>;
     if (dict_blocks == 0) {
         const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
         dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -972,7 +984,7 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
                        (const double *)d_val, (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,
                        (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval, (int)dict_plane_a,
                        (int)dict_plane_b, (int)dict_plane_f, cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials,
-                       (int64_t)0, n, 0);
+                       (int64_t)0, n);
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;
@@ -993,15 +1005,14 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
         const int w = dict_window_per_thread(wlen, kPlanesBlock);
-        // A wavefront whose 128 rows share one pattern keeps that pattern's values and offsets in registers.  The rows at
-        // the ends of a grid line have patterns of their own, so this pays when the lines are long (512^3: 6 of 8
-        // wavefronts, 0.549 -> 0.521 ms; 256^3: 2 of 4, 0.077 -> 0.078 ms): on from an in-plane reach of 384 rows.
-        // LANCZOS_HIP_DICT_CACHE=0 / 1 overrides (the results are the same bits).
+        // A wavefront whose 128 rows share one pattern can keep that pattern's values (1) or values and window offsets (2)
+        // in registers; LANCZOS_HIP_DICT_CACHE = 0 / 1 / 2 chooses (the results are the same bits).
         const char *cache_env = getenv("LANCZOS_HIP_DICT_CACHE");
-        const int cache_patterns = cache_env && *cache_env ? atoi(cache_env) != 0 : dict_halo >= 384;
-        const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, false>
-                                        : w <= 6 ? k_spmv_dict_planes<6, false>
-                                                 : k_spmv_dict_planes<10, false>;
+        const int cache = cache_env && *cache_env ? std::min(std::max(atoi(cache_env), 0), 2) : kDictCacheDefault(dict_halo);
+        const DictPlanesKernel kernel =
+            w <= 4   ? (cache == 2 ? k_spmv_dict_planes<4, false, 2> : cache == 1 ? k_spmv_dict_planes<4, false, 1> : k_spmv_dict_planes<4, false, 0>)
+            : w <= 6 ? (cache == 2 ? k_spmv_dict_planes<6, false, 2> : cache == 1 ? k_spmv_dict_planes<6, false, 1> : k_spmv_dict_planes<6, false, 0>)
+                     : (cache == 2 ? k_spmv_dict_planes<10, false, 2> : cache == 1 ? k_spmv_dict_planes<10, false, 1> : k_spmv_dict_planes<10, false, 0>);
         if (dict_blocks == 0) {
             const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
             dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -1013,7 +1024,7 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, nnz,
                            (const int32_t *)nullptr, (const double *)nullptr, pat, dict_patterns, dict_stride, dict_halo,
                            dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
-                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi, cache_patterns);
+                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);
     } else if (form == 1) {
         // loads one step ahead; 16-byte loads when no pair of doubles can straddle the start of x
         // (LANCZOS_HIP_DICT_WIDE=0: never); 512 threads, two rows per thread (LANCZOS_HIP_DICT_BLOCK=256: four)

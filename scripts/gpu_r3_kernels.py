@@ -113,40 +113,42 @@ def fuse_form(sizes):
 
 
 def dict_cache_form(sizes):
-    """The plane-walking dictionary SpMV with the wavefront's pattern kept in registers (LANCZOS_HIP_DICT_CACHE, read at
-    every launch) against the form that reads the tables for every row: same bits on several grids, then HIP-event time
-    per launch on the given grids, alternating."""
+    """The plane-walking dictionary SpMV with a wavefront's pattern kept in registers (LANCZOS_HIP_DICT_CACHE: 0 not,
+    1 its values, 2 values and window offsets; each a kernel of its own, with its own register count and grid): same
+    bits on several grids, then HIP-event time per launch on the given grids, an engine per form, three rounds."""
     rng = np.random.default_rng(0)
     out = {"bitwise": {}, "timing": {}}
-    for N in (20, 33, 64, 97):
+    for N in (64, 97, 130):
         a = la.synth_laplacian(3, N)
         x = rng.standard_normal(a.dimension)
-        with la.Engine(a, 3, reorth="none", spmv="dict") as e:
-            os.environ["LANCZOS_HIP_DICT_CACHE"] = "0"
-            y0 = e.spmv(x)
-            os.environ["LANCZOS_HIP_DICT_CACHE"] = "1"
-            y1 = e.spmv(x)
-            name = e.spmv_name
-        out["bitwise"][f"lap3d-{N} {name}"] = bool(y0.tobytes() == y1.tobytes())
-        print(N, name, "bitwise equal:", y0.tobytes() == y1.tobytes(), flush=True)
+        ys = {}
+        for c in ("0", "1", "2"):
+            os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+            with la.Engine(a, 3, reorth="none", spmv="dict") as e:
+                ys[c] = e.spmv(x)
+                name = e.spmv_name
+        same = ys["0"].tobytes() == ys["1"].tobytes() == ys["2"].tobytes()
+        out["bitwise"][f"lap3d-{N} {name}"] = bool(same)
+        print(N, name, "bitwise equal:", same, flush=True)
     for N in sizes:
         a = la.synth_laplacian(3, N)
         res = {}
-        with la.Engine(a, 4, reorth="none", spmv="dict", profile=True) as e:
-            for rnd in range(3):
-                for c in ("0", "1"):
-                    os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+        for rnd in range(3):
+            for c in ("0", "1", "2"):
+                os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+                with la.Engine(a, 4, reorth="none", spmv="dict", profile=True) as e:
                     e.set_start_seed(1)
-                    e.run(3)
+                    e.run(5)
                     e.profile_reset()
                     e.run(100)
                     p = e.profile()
                     res.setdefault(c, []).append(p["spmv"]["ms"] / 100)
-            bytes_ = p["spmv"]["bytes"] / 100
-            name = e.spmv_name
+                    bytes_ = p["spmv"]["bytes"] / 100
+                    name = e.spmv_name
         for c, v in res.items():
             out["timing"][f"{N}^3 cache={c}"] = {"ms_per_spmv": v, "best_TBps": bytes_ / min(v) / 1e9}
             print(f"{N}^3 {name} cache={c}: {[round(t, 4) for t in v]} ms per SpMV, best {bytes_ / min(v) / 1e9:.3f} TB/s", flush=True)
+    os.environ.pop("LANCZOS_HIP_DICT_CACHE", None)
     return out
 
 

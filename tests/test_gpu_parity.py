@@ -944,8 +944,8 @@ def test_c_program_with_a_matrix_free_plugin(gpu):
 
 def test_dictionary_plane_walk_with_the_pattern_in_registers_gives_the_same_bits(gpu, monkeypatch):
     """The plane-walking dictionary SpMV keeps a wavefront's pattern in registers when all its rows share one (on by
-    default for long grid lines; LANCZOS_HIP_DICT_CACHE forces it on or off): the same bits as the form that reads the
-    tables for every row, on grids whose lines end inside, at the end of and across wavefronts, and against the
+    default for long grid lines; LANCZOS_HIP_DICT_CACHE: 0 not, 1 its values, 2 values and window offsets, each a
+    kernel of its own): the same bits as the form that reads the tables for every row, on grids whose lines end inside, at the end of and across wavefronts, and against the
     oracle's product (src/crs.c:155-178)."""
     rng = np.random.default_rng(4)
     for N in (64, 70, 97, 129):
@@ -953,11 +953,11 @@ def test_dictionary_plane_walk_with_the_pattern_in_registers_gives_the_same_bits
         x = rng.standard_normal(a.dimension)
         with la.Engine(a, 3, reorth="none", spmv="dict") as e:
             got = {}
-            for c in ("0", "1"):
+            for c in ("0", "1", "2"):
                 monkeypatch.setenv("LANCZOS_HIP_DICT_CACHE", c)
                 got[c] = e.spmv(x)
             assert e.spmv_name == "dict27p"
-        assert got["0"].tobytes() == got["1"].tobytes(), N
+        assert got["0"].tobytes() == got["1"].tobytes() == got["2"].tobytes(), N
         want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
         assert np.max(np.abs(got["1"] - want)) <= 8 * np.finfo(float).eps * np.max(np.abs(want)), N
 
