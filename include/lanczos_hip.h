@@ -117,9 +117,10 @@ typedef struct crs {
  *                          dictionary SpMV's plane-walking form (3-D grids), its forms that load one step
  *                          ahead, and their 16-byte loads (for comparison; the results are the same bits);
  *                          LANCZOS_HIP_DICT_BLOCK 256 runs the ahead form with 256-thread workgroups
- *   LANCZOS_HIP_DICT_CACHE 0 / 1 / 2: the plane-walking dictionary SpMV keeps nothing / the values / the values and window
- *                          offsets of a wavefront's pattern in registers when all its rows share one (default: 2 for
- *                          grid lines of 384 rows or more, else 0; the same bits in every form)
+ *   LANCZOS_HIP_DICT_SPAN  1024 / 2048: rows of a plane per step of the plane-walking dictionary SpMV (default: 2048 for grid
+ *                          lines of 384 rows or more, else 1024); LANCZOS_HIP_DICT_CACHE 0 / 1 / 2: it keeps nothing / the
+ *                          values / the values and window offsets of a wavefront's pattern in registers when all its rows
+ *                          share one (default 0).  The same bits in every form; read when an engine first multiplies
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up chose (schedule, block shape, pieces,
  *                          entries kept out of the packed stream) on stderr
  */

@@ -425,9 +425,9 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
 // for the three positions of the ring are built once per workgroup; the step is instantiated per position.
 constexpr int kPlanesBlock = 512;
 
-static size_t dict_planes_lds_bytes(int halo, int patterns, int stride) {
-    return sizeof(double) * (size_t)(3 * (kDictSpan + 2 * halo) + kDictSpan) + (size_t)patterns * stride * (8 + 3 * 4) +
-           sizeof(uint16_t) * kDictSpan + 16;
+static size_t dict_planes_lds_bytes(int halo, int patterns, int stride, int span = kDictSpan) {
+    return sizeof(double) * (size_t)(3 * (span + 2 * halo) + span) + (size_t)patterns * stride * (8 + 3 * 4) +
+           sizeof(uint16_t) * span + 16;
 }
 
 // CRS_VALUES: the row-wise CRS product as a plane walk.  When the rows' column OFFSETS repeat as patterns although
@@ -438,26 +438,29 @@ static size_t dict_planes_lds_bytes(int halo, int patterns, int stride) {
 // CACHE (dictionary form only): 0 every row reads its pattern's values and window offsets from the LDS tables; 1 a
 // wavefront whose rows share one pattern keeps the values in registers; 2 the values and the offsets of the three ring
 // positions (40 registers more: two workgroups per CU where the other forms have three).
-template <int WPT, bool CRS_VALUES, int CACHE>
-__global__ void __launch_bounds__(kPlanesBlock)
+// SPAN: rows of a plane per step, 1024 or 2048, two per thread.  A step loads SPAN + 2 halo doubles of x for SPAN rows:
+// the longer span re-reads less (512^3: 1.5 times x in place of 2), at the price of LDS (one workgroup of 1024
+// threads per CU where the short span has two or three of 512).
+template <int WPT, bool CRS_VALUES, int CACHE, int SPAN>
+__global__ void __launch_bounds__(SPAN / 2)
 k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restrict__ rp, const double *__restrict__ val, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                    int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
                    const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
                    int64_t dot_lo, int64_t dot_hi) {
-    constexpr int BLOCK = kPlanesBlock, ROWS = kDictSpan / BLOCK;
+    constexpr int BLOCK = SPAN / 2, ROWS = SPAN / BLOCK;
     static_assert(ROWS == 2, "two rows per thread");
     extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
     __shared__ double red[BLOCK / 64];
     const int tid = threadIdx.x;
-    const int wlen = kDictSpan + 2 * halo;
+    const int wlen = SPAN + 2 * halo;
     const int tab = patterns * stride;
     double *s_zero = win + 3 * wlen;
-    double *s_val = s_zero + kDictSpan;
+    double *s_val = s_zero + SPAN;
     int32_t *s_idx = reinterpret_cast<int32_t *>(s_val + tab);
     uint16_t *s_pat = reinterpret_cast<uint16_t *>(s_idx + 3 * tab + ((3 * tab) & 1));
-    int32_t *s_len = reinterpret_cast<int32_t *>(s_pat + kDictSpan);   // CRS_VALUES only
+    int32_t *s_len = reinterpret_cast<int32_t *>(s_pat + SPAN);   // CRS_VALUES only
     if (CRS_VALUES)
         for (int i = tid; i < patterns; i += BLOCK) s_len[i] = dlen[i];
     for (int i = tid; i < tab; i += BLOCK) {
@@ -477,7 +480,7 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
             s_idx[rot * tab + i] = e;
         }
     }
-    for (int i = tid; i < kDictSpan; i += BLOCK) s_zero[i] = 0.0;
+    for (int i = tid; i < SPAN; i += BLOCK) s_zero[i] = 0.0;
     // work item = (column of steps, segment of planes); XCD b % 8 takes a contiguous eighth of the items
     const int64_t items = (int64_t)cols * segs;
     const int64_t per_xcd = (items + 7) >> 3;
@@ -505,11 +508,11 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
         const bool use_cache = !CRS_VALUES && CACHE != 0 && stride <= 8;
         // a slab's remote planes: x[r + far_a] for the rows r of plane 0, x[r + far_b] for those of the last plane
         // (a plane need not be a whole number of steps: its last column of steps has fewer rows, `lim`)
-        const int lim = min(kDictSpan, plane_rows - col * kDictSpan);
+        const int lim = min(SPAN, plane_rows - col * SPAN);
         auto row_of = [&](int z) -> int64_t {
-            int64_t row = (int64_t)z * plane_rows + (int64_t)col * kDictSpan;
-            if (z < 0 && far_a != INT32_MIN) row = far_a + (int64_t)col * kDictSpan;
-            if (z >= planes && far_b != INT32_MIN) row = far_b + (int64_t)(planes - 1) * plane_rows + (int64_t)col * kDictSpan;
+            int64_t row = (int64_t)z * plane_rows + (int64_t)col * SPAN;
+            if (z < 0 && far_a != INT32_MIN) row = far_a + (int64_t)col * SPAN;
+            if (z >= planes && far_b != INT32_MIN) row = far_b + (int64_t)(planes - 1) * plane_rows + (int64_t)col * SPAN;
             return row;
         };
         // a plane outside the grid, or rows past the end, read as zeros (or as rows no entry refers to)
@@ -653,8 +656,11 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0)
-        partials[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    if (threadIdx.x == 0) {
+        double t = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+        if constexpr (BLOCK == 1024) t += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+        partials[blockIdx.x] = t;
+    }
 }
 
 void Engine::free_dict() {
@@ -668,6 +674,7 @@ void Engine::free_dict() {
     d_dval = nullptr;
     dict_patterns = 0;
     dict_blocks = 0;
+    dict_span = 0;
 }
 
 // dict_patterns > 0 afterwards when the matrix is a dictionary of at most 65535 row patterns of at
@@ -925,8 +932,11 @@ using DictPlanesKernel = void (*)(int64_t, int64_t, int64_t, const int32_t *, co
                                   int, const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
                                   const double *, const double *, double *, double *, int64_t, int64_t);
 
-// which register form of the plane walk runs when LANCZOS_HIP_DICT_CACHE does not say (measured on 256^3 and 512^3)
-static int kDictCacheDefault(int halo) { return halo >= 384 ? 2 : 0; }
+// The plane walk's two knobs when the environment does not set them, from measurements on 256^3 and 512^3 (ms per SpMV,
+// span 1024 / 2048 x tables / registers): 256^3 0.0713 0.0784 | 0.0718 0.0772; 512^3 0.534 0.515 | 0.510 0.539.
+// Long grid lines take the long span (less of x read twice), nobody takes the register form by default.
+static int kDictCacheDefault(int halo) { (void)halo; return 0; }
+static int dict_span_default(int halo) { return halo >= 384 ? 2048 : kDictSpan; }
 
 // window doubles per thread (even: loaded in pairs) for a window of `wlen` doubles and `block` threads
 static int dict_window_per_thread(int wlen, int block) { return 2 * ((wlen / 2 + block - 1) / block); }
@@ -969,9 +979,9 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
     const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
     const size_t lds = pdict_lds_bytes(dict_halo, dict_patterns, dict_stride);
     const int w = dict_window_per_thread(wlen, kPlanesBlock);
-    const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, true, 0>
-                                 : w <= 6 ? k_spmv_dict_planes<6, true, 0>
-                                          : k_spmv_dict_planes<10, true, 0>;
+    const DictPlanesKernel kernel = w <= 4   ? k_spmv_dict_planes<4, true, 0, kDictSpan>
+                                 : w <= 6 ? k_spmv_dict_planes<6, true, 0, kDictSpan>
+                                          : k_spmv_dict_planes<10, true, 0, kDictSpan>;
     if (dict_blocks == 0) {
         const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
         dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -1001,27 +1011,37 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
     if (form == 2) {
         // a grid in three dimensions, walked plane by plane; the grid is one round of resident workgroups, the
         // planes cut into as many segments as that takes (at least three planes each)
-        const int cols = (dict_plane_f + kDictSpan - 1) / kDictSpan;
+        if (dict_span == 0) {
+            // rows per step, chosen once per engine: LANCZOS_HIP_DICT_SPAN = 1024 / 2048, else by the in-plane reach
+            const char *span_env = getenv("LANCZOS_HIP_DICT_SPAN");
+            dict_span = span_env && atoi(span_env) == 2048 ? 2048 : span_env && atoi(span_env) == 1024 ? 1024 : dict_span_default(dict_halo);
+            if (dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride, dict_span) > 160 * 1024 - 512) dict_span = kDictSpan;
+            // a wavefront whose rows share one pattern can keep that pattern's values and window offsets in registers:
+            // LANCZOS_HIP_DICT_CACHE = 0 / 1 / 2 (tables / values / values and offsets; the same bits)
+            const char *cache_env = getenv("LANCZOS_HIP_DICT_CACHE");
+            dict_cache = cache_env && *cache_env ? std::min(std::max(atoi(cache_env), 0), 2) : kDictCacheDefault(dict_halo);
+        }
+        const int span = dict_span, block = span / 2, cache = dict_cache;
+        const int wlen_p = span + 2 * dict_halo;
+        const int cols = (dict_plane_f + span - 1) / span;
         const int planes = (int)((n + dict_plane_f - 1) / dict_plane_f);
-        const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride);
-        const int w = dict_window_per_thread(wlen, kPlanesBlock);
-        // A wavefront whose 128 rows share one pattern can keep that pattern's values (1) or values and window offsets (2)
-        // in registers; LANCZOS_HIP_DICT_CACHE = 0 / 1 / 2 chooses (the results are the same bits).
-        const char *cache_env = getenv("LANCZOS_HIP_DICT_CACHE");
-        const int cache = cache_env && *cache_env ? std::min(std::max(atoi(cache_env), 0), 2) : kDictCacheDefault(dict_halo);
-        const DictPlanesKernel kernel =
-            w <= 4   ? (cache == 2 ? k_spmv_dict_planes<4, false, 2> : cache == 1 ? k_spmv_dict_planes<4, false, 1> : k_spmv_dict_planes<4, false, 0>)
-            : w <= 6 ? (cache == 2 ? k_spmv_dict_planes<6, false, 2> : cache == 1 ? k_spmv_dict_planes<6, false, 1> : k_spmv_dict_planes<6, false, 0>)
-                     : (cache == 2 ? k_spmv_dict_planes<10, false, 2> : cache == 1 ? k_spmv_dict_planes<10, false, 1> : k_spmv_dict_planes<10, false, 0>);
+        const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride, span);
+        const int w = dict_window_per_thread(wlen_p, block);
+#define LZ_PLANES_C(W_, S_) \
+    (cache == 2 ? k_spmv_dict_planes<W_, false, 2, S_> : cache == 1 ? k_spmv_dict_planes<W_, false, 1, S_> : k_spmv_dict_planes<W_, false, 0, S_>)
+#define LZ_PLANES(W_) (span == 2048 ? LZ_PLANES_C(W_, 2048) : LZ_PLANES_C(W_, 1024))
+        const DictPlanesKernel kernel = w <= 4 ? LZ_PLANES(4) : w <= 6 ? LZ_PLANES(6) : LZ_PLANES(10);
+#undef LZ_PLANES
+#undef LZ_PLANES_C
         if (dict_blocks == 0) {
-            const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, kPlanesBlock, lds), max_blocks);
+            const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, block, lds), max_blocks);
             dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
             dict_seg_len = (planes + dict_segs - 1) / dict_segs;
             dict_segs = (planes + dict_seg_len - 1) / dict_seg_len;
             dict_blocks = (int)(((int64_t)cols * dict_segs + 7) / 8 * 8);
         }
         *nparts = dict_blocks;
-        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(kPlanesBlock), lds, stream, n, n_ext, nnz,
+        hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(block), lds, stream, n, n_ext, nnz,
                            (const int32_t *)nullptr, (const double *)nullptr, pat, dict_patterns, dict_stride, dict_halo,
                            dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
                            cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);

@@ -130,6 +130,7 @@ struct Engine {
     bool pdict = false;        // the row-wise CRS SpMV runs as a plane walk over such a dictionary
     int dict_blocks = 0;       // grid of the ahead-of-time form: one round of resident workgroups
     int dict_segs = 0, dict_seg_len = 0;   // plane-walking form: segments of planes per column of steps
+    int dict_span = 0, dict_cache = 0;     // plane-walking form: rows per step (0: not chosen yet) and its register form
     int32_t dict_plane_f = 0;  // plane-walking form: rows per plane (0: not a grid of whole-step planes)
     int32_t dict_plane_a = 0, dict_plane_b = 0;  // a slab's offsets to the remote planes (INT32_MIN: none)
     int dict_far_count = -1;   // distinct column offsets beyond the LDS window (-1: more than two)

@@ -113,42 +113,50 @@ def fuse_form(sizes):
 
 
 def dict_cache_form(sizes):
-    """The plane-walking dictionary SpMV with a wavefront's pattern kept in registers (LANCZOS_HIP_DICT_CACHE: 0 not,
-    1 its values, 2 values and window offsets; each a kernel of its own, with its own register count and grid): same
-    bits on several grids, then HIP-event time per launch on the given grids, an engine per form, three rounds."""
+    """The plane-walking dictionary SpMV: 1024 or 2048 rows of a plane per step (LANCZOS_HIP_DICT_SPAN), a wavefront's
+    pattern kept in registers or not (LANCZOS_HIP_DICT_CACHE); each combination a kernel of its own, chosen when an engine
+    first multiplies.  Same bits on several grids, then HIP-event time per launch on the given grids, an engine per form,
+    three rounds."""
     rng = np.random.default_rng(0)
+    forms = [("1024", "0"), ("1024", "2"), ("2048", "0"), ("2048", "2")]
     out = {"bitwise": {}, "timing": {}}
-    for N in (64, 97, 130):
+
+    def setenv(span, c):
+        os.environ["LANCZOS_HIP_DICT_SPAN"] = span
+        os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+
+    for N in (64, 67, 97, 130):
         a = la.synth_laplacian(3, N)
         x = rng.standard_normal(a.dimension)
-        ys = {}
-        for c in ("0", "1", "2"):
-            os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+        ys = []
+        for span, c in forms:
+            setenv(span, c)
             with la.Engine(a, 3, reorth="none", spmv="dict") as e:
-                ys[c] = e.spmv(x)
+                ys.append(e.spmv(x).tobytes())
                 name = e.spmv_name
-        same = ys["0"].tobytes() == ys["1"].tobytes() == ys["2"].tobytes()
+        same = all(y == ys[0] for y in ys)
         out["bitwise"][f"lap3d-{N} {name}"] = bool(same)
         print(N, name, "bitwise equal:", same, flush=True)
     for N in sizes:
         a = la.synth_laplacian(3, N)
         res = {}
         for rnd in range(3):
-            for c in ("0", "1", "2"):
-                os.environ["LANCZOS_HIP_DICT_CACHE"] = c
+            for span, c in forms:
+                setenv(span, c)
                 with la.Engine(a, 4, reorth="none", spmv="dict", profile=True) as e:
                     e.set_start_seed(1)
                     e.run(5)
                     e.profile_reset()
                     e.run(100)
                     p = e.profile()
-                    res.setdefault(c, []).append(p["spmv"]["ms"] / 100)
+                    res.setdefault((span, c), []).append(p["spmv"]["ms"] / 100)
                     bytes_ = p["spmv"]["bytes"] / 100
                     name = e.spmv_name
-        for c, v in res.items():
-            out["timing"][f"{N}^3 cache={c}"] = {"ms_per_spmv": v, "best_TBps": bytes_ / min(v) / 1e9}
-            print(f"{N}^3 {name} cache={c}: {[round(t, 4) for t in v]} ms per SpMV, best {bytes_ / min(v) / 1e9:.3f} TB/s", flush=True)
+        for (span, c), v in res.items():
+            out["timing"][f"{N}^3 span={span} cache={c}"] = {"ms_per_spmv": v, "best_TBps": bytes_ / min(v) / 1e9}
+            print(f"{N}^3 {name} span={span} cache={c}: {[round(t, 4) for t in v]} ms per SpMV, best {bytes_ / min(v) / 1e9:.3f} TB/s", flush=True)
     os.environ.pop("LANCZOS_HIP_DICT_CACHE", None)
+    os.environ.pop("LANCZOS_HIP_DICT_SPAN", None)
     return out
 
 

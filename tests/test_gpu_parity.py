@@ -942,24 +942,33 @@ def test_c_program_with_a_matrix_free_plugin(gpu):
     assert len(eig) == 3 and np.max(np.abs(np.array(eig) - o.eigenvalues)) < 5e-12   # printed at %.12f
 
 
-def test_dictionary_plane_walk_with_the_pattern_in_registers_gives_the_same_bits(gpu, monkeypatch):
-    """The plane-walking dictionary SpMV keeps a wavefront's pattern in registers when all its rows share one (on by
-    default for long grid lines; LANCZOS_HIP_DICT_CACHE: 0 not, 1 its values, 2 values and window offsets, each a
-    kernel of its own): the same bits as the form that reads the tables for every row, on grids whose lines end inside, at the end of and across wavefronts, and against the
-    oracle's product (src/crs.c:155-178)."""
+def test_dictionary_plane_walk_forms_give_the_same_bits(gpu, monkeypatch):
+    """The plane-walking dictionary SpMV in its forms -- 1024 or 2048 rows of a plane per step (LANCZOS_HIP_DICT_SPAN; the long
+    span is the default for long grid lines), a wavefront's pattern read from the LDS tables for every row or kept in registers
+    (LANCZOS_HIP_DICT_CACHE 0 / 1 / 2), each a kernel of its own chosen when an engine first multiplies: the same bits in
+    every form, on grids whose lines end inside, at the end of and across wavefronts and steps, and against the oracle's
+    product (src/crs.c:155-178).  Also as row slabs' engines see it: through a run of a few steps."""
     rng = np.random.default_rng(4)
     for N in (64, 70, 97, 129):
         a = la.synth_laplacian(3, N)
         x = rng.standard_normal(a.dimension)
-        with la.Engine(a, 3, reorth="none", spmv="dict") as e:
-            got = {}
+        got, runs = {}, {}
+        for span in ("1024", "2048"):
             for c in ("0", "1", "2"):
+                monkeypatch.setenv("LANCZOS_HIP_DICT_SPAN", span)
                 monkeypatch.setenv("LANCZOS_HIP_DICT_CACHE", c)
-                got[c] = e.spmv(x)
-            assert e.spmv_name == "dict27p"
-        assert got["0"].tobytes() == got["1"].tobytes() == got["2"].tobytes(), N
+                with la.Engine(a, 6, reorth="full", spmv="dict") as e:
+                    got[span, c] = e.spmv(x)
+                    e.set_start_seed(3)
+                    runs[span, c] = e.run(5)
+                    assert e.spmv_name == "dict27p"
+        first = got["1024", "0"]
+        assert all(v.tobytes() == first.tobytes() for v in got.values()), N
+        a0, b0 = runs["1024", "0"]
+        for (span, c), (al, be) in runs.items():      # the fused dot product sums per workgroup: another grid, another order
+            assert rel_err(al, a0) < 1e-13 and rel_err(be, b0) < 1e-13, (N, span, c)
         want = oracle.matvec_crs(a.row_head_indexes, a.column_index, a.values, x)
-        assert np.max(np.abs(got["1"] - want)) <= 8 * np.finfo(float).eps * np.max(np.abs(want)), N
+        assert np.max(np.abs(first - want)) <= 8 * np.finfo(float).eps * np.max(np.abs(want)), N
 
 
 def test_c_program_walks_the_abi(gpu, tmp_path):
