@@ -121,6 +121,8 @@ typedef struct crs {
  *                          lines of 384 rows or more, else 1024); LANCZOS_HIP_DICT_CACHE 0 / 1 / 2: it keeps nothing / the
  *                          values / the values and window offsets of a wavefront's pattern in registers when all its rows
  *                          share one (default 0).  The same bits in every form; read when an engine first multiplies
+ *   LANCZOS_HIP_NT_STORES  0 / 1: the recurrence with deferred normalisation writes its vector cacheably / past the caches
+ *                          (default: past them from 32 MiB per vector on); read at every launch
  *   LANCZOS_HIP_VERBOSE    1 prints what the tiled SpMV's set-up chose (schedule, block shape, pieces,
  *                          entries kept out of the packed stream) on stderr
  */

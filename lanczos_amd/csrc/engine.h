@@ -212,6 +212,9 @@ struct Engine {
     int phase_recur_lazy(double *red);
     int phase_lazy_norm(double *red);
     int phase_lazy_close(double *red);
+    bool nt_stores() const;             // vectors too long for the caches: the vector kernels write past them
+    void (*recur_lazy_kernel() const)(double2 *, const double2 *, const double2 *, int64_t, int, const double *, int, const double *, int,
+                                      double *, double *, double *, double *);
     int enqueue_iteration();
     int combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld);
     int restart(int p, const double *coef_host, double last_coupling);

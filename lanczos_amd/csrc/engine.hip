@@ -517,6 +517,22 @@ int Engine::vec_blocks() const {
     return (int)std::min<int64_t>(max_blocks, (n2 + kBlock - 1) / kBlock);
 }
 
+// The recurrence with deferred normalisation writes the vector the next product reads.  While a vector fits the L2s that
+// store is best left cacheable; from 32 MiB on it is written past the caches, which also spares the next kernel the
+// write-back of those lines: 256^3, SpMV + vector step on the dictionary 5990 -> 6310 it/s with both kernels faster
+// (0.0718 -> 0.0672 and 0.0829 -> 0.0789 ms), 512^3 791 -> 845; 100^3 2 % slower, 128^3 equal.  On the row-wise CRS
+// kernels, which gather x through the caches, the recurrence gains 4.8 us and the product loses 2.6 (2296 -> 2308 it/s).
+// The same store in that SpMV's own y changed nothing (0.3425 ms either way) and is not there.
+// LANCZOS_HIP_NT_STORES = 0 / 1 overrides, read at every launch.
+bool Engine::nt_stores() const {
+    const char *env = getenv("LANCZOS_HIP_NT_STORES");
+    return env && *env ? atoi(env) != 0 : 8.0 * (double)n >= 32.0 * 1048576.0;
+}
+
+using RecurLazyKernel = void (*)(double2 *, const double2 *, const double2 *, int64_t, int, const double *, int, const double *, int,
+                                 double *, double *, double *, double *);
+RecurLazyKernel Engine::recur_lazy_kernel() const { return nt_stores() ? k_recur_lazy<true> : k_recur_lazy<false>; }
+
 // grid of the recurrence and scaling kernels: whole tiles, two workgroups per CU (512^3, k_recur_lazy with
 // 2 / 4 / 8 per CU: 0.741 / 0.785 / 0.766 ms; LANCZOS_HIP_VEC_WG_PER_CU for measurements)
 int Engine::recur_blocks() const {
@@ -913,7 +929,7 @@ int Engine::phase_recur_lazy(double *red) {
     const int blocks = recur_blocks();
     {
         ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
-        hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
+        hipLaunchKernelGGL(recur_lazy_kernel(), dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
                            (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, k,
                            (const double *)red, 1, (const double *)(red + 1), 1, norm_parts(k), d_alpha, d_beta,
                            h_hist);
@@ -1080,7 +1096,7 @@ int Engine::enqueue_iteration() {
         const int blocks = recur_blocks();
         {
             ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
-            hipLaunchKernelGGL(k_recur_lazy, dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
+            hipLaunchKernelGGL(recur_lazy_kernel(), dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
                                (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, k,
                                (const double *)d_partials, alpha_count, (const double *)norm_parts(k - 1), norm_count,
                                norm_parts(k), d_alpha, d_beta, h_hist);

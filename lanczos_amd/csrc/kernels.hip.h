@@ -1037,6 +1037,8 @@ k_scale(double2 *__restrict__ w, int64_t n2, const double *__restrict__ norm_par
 // between launches); workgroup 0 records it.  beta_{k-2} is read from the
 // history, written by the previous launch.
 // ---------------------------------------------------------------------------
+// NT_STORE: u_{k+1} is written past the caches (vectors that do not fit them: Engine::nt_stores)
+template <bool NT_STORE>
 __global__ void __launch_bounds__(kBlock)
 k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const double2 *__restrict__ uprev,
              int64_t n2, int k, const double *__restrict__ dot_parts, int dot_count,
@@ -1068,7 +1070,8 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
             for (int u = 0; u < kEPT2; ++u) {
                 a[u].x = (s_k * a[u].x - c_p * p[u].x) - c_k * q[u].x;
                 a[u].y = (s_k * a[u].y - c_p * p[u].y) - c_k * q[u].y;
-                w[base + u * kBlock] = a[u];
+                if constexpr (NT_STORE) st_stream(w + base + u * kBlock, a[u]);
+                else w[base + u * kBlock] = a[u];
                 acc += a[u].x * a[u].x + a[u].y * a[u].y;
             }
         }
@@ -1084,7 +1087,8 @@ k_recur_lazy(double2 *__restrict__ w, const double2 *__restrict__ uk, const doub
             for (int u = 0; u < kEPT2; ++u) {
                 a[u].x = a[u].x - c_k * q[u].x;
                 a[u].y = a[u].y - c_k * q[u].y;
-                w[base + u * kBlock] = a[u];
+                if constexpr (NT_STORE) st_stream(w + base + u * kBlock, a[u]);
+                else w[base + u * kBlock] = a[u];
                 acc += a[u].x * a[u].x + a[u].y * a[u].y;
             }
         }
