@@ -290,12 +290,18 @@ def big_laplacian_section(la, torch, N: int, steps: int = 100) -> dict:
         t_up = time.perf_counter() - t0
         e.set_start_seed(123456789)
         e.run(5)
-        e.profile_reset()
+        # timed with no kernel bracketed by events, then the same steps again with all of them for the kernel figures
+        e.profile_select(())
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         e.run(steps)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        e.profile_select(None)
+        e.set_start_seed(123456789)
+        e.run(5)
+        e.profile_reset()
+        e.run(steps)
         prof = e.profile()
         name = e.spmv_name
     fmt_iter = prof["spmv"]["bytes"] / steps + 32.0 * n   # the format's SpMV bytes + the recurrence's 32 n
@@ -360,6 +366,12 @@ def single_gpu(args, keeper=None) -> dict:
     eng.set_start(v0)
     if W > 0:
         eng.run(W)
+    # The timed run brackets with HIP events only the kernel classes one of which is the dominant one -- the two
+    # reorthogonalisation kernels, or the product and the recurrence when there is no reorthogonalisation: two events
+    # around every launch of every class cost the run 6 % at 20 steps (1460 against 1550 it/s).  The roofline record
+    # comes from this run; the table of all classes from a second pass over the same K steps, every class timed.
+    timed_classes = ("spmv", "recur") if args.reorth in ("none", "selective") else ("dots", "update")
+    eng.profile_select(timed_classes)
     eng.set_start(v0)
     eng.profile_reset()
     torch.cuda.synchronize()
@@ -367,9 +379,18 @@ def single_gpu(args, keeper=None) -> dict:
     alpha, beta = eng.run(K)          # enqueues K iterations, then drains the stream
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = eng.profile()
+    prof_timed = {k: v for k, v in eng.profile().items() if k in timed_classes}
     spmv_name_main = eng.spmv_name
     ritz = la.ritz_values(alpha, beta, K, 4)
+    eng.profile_select(None)
+    eng.set_start(v0)
+    eng.profile_reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run(K)
+    torch.cuda.synchronize()
+    dt_all_timed = time.perf_counter() - t0
+    prof = eng.profile()
 
     # the SpMV + vector step on its own (no reorthogonalisation): the part of the
     # iteration whose bytes do not grow with k
@@ -386,13 +407,24 @@ def single_gpu(args, keeper=None) -> dict:
             os.environ.pop("LANCZOS_HIP_ROWS_PLANES", None)
         e2.set_start(v0)
         e2.run(5)
-        e2.profile_reset()
-        torch.cuda.synchronize()
         S = 100
+        # timed with no class bracketed by events (they cost this run of short kernels 6-9 %), then the same S steps
+        # again with all of them for the per-kernel figures
+        e2.profile_select(())
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         e2.run(S)
         torch.cuda.synchronize()
         dt2 = time.perf_counter() - t1
+        e2.profile_select(None)
+        e2.set_start(v0)
+        e2.run(5)
+        e2.profile_reset()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        e2.run(S)
+        torch.cuda.synchronize()
+        dt2_events = time.perf_counter() - t1
         p2 = e2.profile()
         name = e2.spmv_name
         e2.close()
@@ -407,6 +439,7 @@ def single_gpu(args, keeper=None) -> dict:
         rec = {
             "iters_per_s": S / dt2,
             "ms_per_iter": dt2 / S * 1e3,
+            "iters_per_s_with_every_kernel_timed": S / dt2_events,
             "spmv_kernel": name,
             "matrix_format": "row-pattern dictionary" if name.startswith("dict") else
                              "CRS values and row offsets + column-offset patterns" if name.startswith("rows") and name.endswith("p")
@@ -464,7 +497,7 @@ def single_gpu(args, keeper=None) -> dict:
             "spmv_kernel": spmv_name,
             "parallelism": "1 GPU",
         },
-        "roofline": roofline_from_profile(prof),
+        "roofline": roofline_from_profile(prof_timed),
         # the SpMV kernel of the timed run, in the bytes of the format it reads
         "spmv_hbm_GBps": (prof["spmv"]["bytes"] / (prof["spmv"]["ms"] * 1e-3) / 1e9) if prof["spmv"]["ms"] > 0 else None,
         "spmv_hbm_kernel": spmv_name_main,
@@ -472,6 +505,10 @@ def single_gpu(args, keeper=None) -> dict:
         "spmv_vector_step": sv,
         "spmv_vector_step_crs": sv_crs,
         "spmv_vector_step_crs_values": sv_crs_planes,
+        # second pass over the same K steps with every kernel class bracketed by events (the timed run brackets only
+        # the classes named in kernel_classes_timed_in_the_timed_run)
+        "kernel_classes_timed_in_the_timed_run": list(timed_classes),
+        "value_with_every_class_timed": K / dt_all_timed,
         "kernel_ms_total": {k: v["ms"] for k, v in prof.items()},
         "kernel_launches": {k: v["launches"] for k, v in prof.items()},
         "kernel_algorithmic_bytes_total": {k: v["bytes"] for k, v in prof.items()},
@@ -519,6 +556,7 @@ def single_gpu(args, keeper=None) -> dict:
         with la.Engine(a, 301, reorth=args.reorth, spmv=args.spmv, profile=True) as ef:
             ef.set_start(v0)
             ef.run(min(W, 5))
+            ef.profile_select(timed_classes)
             ef.set_start(v0)
             ef.profile_reset()
             torch.cuda.synchronize()
@@ -526,7 +564,7 @@ def single_gpu(args, keeper=None) -> dict:
             af, bf = ef.run(300)
             torch.cuda.synchronize()
             dtf = time.perf_counter() - t0
-            rf = roofline_from_profile(ef.profile())
+            rf = roofline_from_profile({k: v for k, v in ef.profile().items() if k in timed_classes})
             rf["traffic"] = measured_traffic(rf["kernel"], args.workload, args.reorth, rf["algorithmic_bytes_per_launch"])
             out["config_300_steps"] = {
                 "steps": 300, "value": 300 / dtf, "unit": "iters/s", "ms_per_step": dtf / 300 * 1e3, "roofline": rf,

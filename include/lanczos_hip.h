@@ -341,6 +341,10 @@ int lanczos_hip_get_vector(lanczos_hip_engine *e, int k, double *out_host);
 int lanczos_hip_profile(const lanczos_hip_engine *e, int kernel_class, double *ms,
                         int64_t *launches, double *bytes);
 void lanczos_hip_profile_reset(lanczos_hip_engine *e);
+/* Which kernel classes are timed (bit LANCZOS_HIP_K_* set: bracketed by two events per launch; default all).  The
+ * events cost a run of short kernels several per cent (256^3 without reorthogonalisation: 6940 it/s with none, 6300
+ * with all), so a timed run selects the classes it reports; launches and bytes are counted for every class. */
+int lanczos_hip_profile_select(lanczos_hip_engine *e, unsigned class_mask);
 
 /* Name of the SpMV kernel variant the engine selected ("dict27", "rows64", "pipe16", "panel16",
  * "merge", "vector8", ...).  LANCZOS_HIP_SPMV_AUTO decides from the matrix as it sits on the device:

@@ -104,6 +104,7 @@ _hip.lanczos_hip_get_vector.argtypes = [C.c_void_p, C.c_int, _dp]
 _hip.lanczos_hip_get_vector.restype = C.c_int
 _hip.lanczos_hip_profile.argtypes = [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_int64), _dp]
 _hip.lanczos_hip_profile.restype = C.c_int
+_hip.lanczos_hip_profile_select.argtypes = [C.c_void_p, C.c_uint]
 _hip.lanczos_hip_profile_reset.argtypes = [C.c_void_p]
 _hip.lanczos_hip_profile_reset.restype = None
 _hip.lanczos_hip_spmv_name.argtypes = [C.c_void_p]
@@ -780,6 +781,12 @@ class Engine:
 
     def profile_reset(self):
         _hip.lanczos_hip_profile_reset(self._h)
+
+    def profile_select(self, classes=None):
+        """The kernel classes (names of KERNEL_CLASSES) whose launches are timed from now on; None: all of them.
+        Launches and bytes are counted for every class."""
+        mask = 0xFFFFFFFF if classes is None else sum(1 << KERNEL_CLASSES.index(c) for c in classes)
+        _check(_hip.lanczos_hip_profile_select(self._h, mask), "lanczos_hip_profile_select")
 
     # phase-level calls for row-partitioned runs; `red` is a device address
     def phase_spmv(self, red: int):

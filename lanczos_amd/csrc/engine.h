@@ -149,6 +149,7 @@ struct Engine {
                            // with a checkpoint so a resumed loop knows which lines were already printed
     // profiling
     bool profile = false;
+    unsigned prof_mask = ~0u;  // kernel classes whose launches are bracketed by events (bytes and launches are counted for all)
     double prof_ms[LANCZOS_HIP_K_COUNT] = {0};
     int64_t prof_launches[LANCZOS_HIP_K_COUNT] = {0};
     double prof_bytes[LANCZOS_HIP_K_COUNT] = {0};

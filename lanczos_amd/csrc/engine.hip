@@ -58,16 +58,20 @@ static int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 struct ProfScope {
     Engine *e;
     int cls;
-    ProfScope(Engine *eng, int c, double bytes) : e(eng), cls(c) {
+    bool timed;
+    ProfScope(Engine *eng, int c, double bytes) : e(eng), cls(c), timed(false) {
         if (!e->profile) return;
         e->prof_bytes[cls] += bytes;
         e->prof_launches[cls] += 1;
+        // two events per launch cost a run of short kernels several per cent: only the selected classes are timed
+        timed = ((e->prof_mask >> cls) & 1u) != 0;
+        if (!timed) return;
         hipEvent_t a = e->take_event();
         (void)hipEventRecord(a, e->stream);
         e->prof_pending.push_back({cls, a, nullptr});
     }
     ~ProfScope() {
-        if (!e->profile) return;
+        if (!timed) return;
         hipEvent_t b = e->take_event();
         (void)hipEventRecord(b, e->stream);
         e->prof_pending.back().stop = b;
@@ -1428,6 +1432,12 @@ void lanczos_hip_profile_reset(lanczos_hip_engine *e) {
         g->prof_launches[i] = 0;
         g->prof_bytes[i] = 0;
     }
+}
+
+int lanczos_hip_profile_select(lanczos_hip_engine *e, unsigned class_mask) {
+    if (!e) return lz::fail("lanczos_hip_profile_select: NULL engine");
+    E(e)->prof_mask = class_mask;
+    return 0;
 }
 
 int lanczos_hip_ritz_vectors(lanczos_hip_engine *eh, int steps, int m, double *eig, double *vectors_host,
