@@ -407,7 +407,7 @@ def single_gpu(args, keeper=None) -> dict:
             os.environ.pop("LANCZOS_HIP_ROWS_PLANES", None)
         e2.set_start(v0)
         e2.run(5)
-        S = 100
+        S = 400   # a run() call costs about 0.6 ms besides its steps (drain, history): 4 % of 100 steps of 0.14 ms, 1 % of 400
         # timed with no class bracketed by events (they cost this run of short kernels 6-9 %), then the same S steps
         # again with all of them for the per-kernel figures
         e2.profile_select(())
