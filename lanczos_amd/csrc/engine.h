@@ -213,6 +213,7 @@ struct Engine {
     int phase_recur_lazy(double *red);
     int phase_lazy_norm(double *red);
     int phase_lazy_close(double *red);
+    int fuse_limit() const;
     bool nt_stores() const;             // vectors too long for the caches: the vector kernels write past them
     void (*recur_lazy_kernel() const)(double2 *, const double2 *, const double2 *, int64_t, int, const double *, int, const double *, int,
                                       double *, double *, double *, double *);

@@ -533,6 +533,13 @@ bool Engine::nt_stores() const {
     return env && *env ? atoi(env) != 0 : 8.0 * (double)n >= 32.0 * 1048576.0;
 }
 
+// how many basis vectors the fused recurrence + dot products kernel takes (beyond: two kernels): 32, the break-even on
+// vectors in HBM; any number while a vector is at most 2 MiB (10 000 rows, 100 steps: 3.91 -> 3.77 ms, 64^3: 8.63 -> 8.47)
+int Engine::fuse_limit() const {
+    if (const char *env = getenv("LANCZOS_HIP_FUSE_MAX")) return atoi(env);
+    return 8.0 * (double)npad <= 2.0 * 1048576.0 ? kMaxDotsSegment : 32;
+}
+
 using RecurLazyKernel = void (*)(double2 *, const double2 *, const double2 *, int64_t, int, const double *, int, const double *, int,
                                  double *, double *, double *, double *);
 RecurLazyKernel Engine::recur_lazy_kernel() const { return nt_stores() ? k_recur_lazy<true> : k_recur_lazy<false>; }
@@ -1124,8 +1131,9 @@ int Engine::enqueue_iteration() {
     // Only while the pass is short: at k = 10 the one sweep saves 0.026 ms of 0.30 (256^3), but with 150 basis
     // vectors behind it the stores of w inside the sweep cost the basis stream 0.15 ms more than k_recur's own
     // pass took (3.18 ms against 2.95 + 0.08); measured break-even near 30 vectors.
-    constexpr int kFuseMaxVectors = 32;
-    if (fuse && blocked && k > 0 && l1 > l0 && l1 - l0 <= kFuseMaxVectors) {
+    // Vectors that sit in the L2s are another matter: there a step is the sum of its launches (about 7 us each), and one
+    // launch less is worth having at any k (fuse_limit).
+    if (fuse && blocked && k > 0 && l1 > l0 && l1 - l0 <= fuse_limit()) {
         reorth_steps += 1;
         int nparts = 0;
         if (int rc = launch_recur_dots(d_partials, alpha_count, l0, l1, d_red)) return rc;

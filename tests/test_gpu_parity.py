@@ -875,16 +875,24 @@ def test_recurrence_fused_with_the_dot_products_gives_the_same_bits(gpu, monkeyp
     for a in (la.synth_laplacian(3, 40), la.synth_laplacian(1, 700), la.synth_random_symmetric(30000, 6, 3)):
         v0 = la.gaussian_fill(5, 0, a.dimension)
         runs = {}
-        for fuse in ("1", "0"):
-            monkeypatch.setenv("LANCZOS_HIP_FUSE_RECUR", fuse)
+        for fuse in ("1", "0", "short"):
+            monkeypatch.setenv("LANCZOS_HIP_FUSE_RECUR", "0" if fuse == "0" else "1")
+            # "1": the rule for vectors in HBM (at most 32 basis vectors ride with the recurrence); "short": the default
+            # for vectors of at most 2 MiB, as these are (every pass fused: such a step is the sum of its launches)
+            if fuse == "1":
+                monkeypatch.setenv("LANCZOS_HIP_FUSE_MAX", "32")
+            else:
+                monkeypatch.delenv("LANCZOS_HIP_FUSE_MAX", raising=False)
             with la.Engine(a, 41, reorth=reorth, profile=True) as e:
                 e.set_start(v0)
                 runs[fuse] = e.run(40)
                 launches = e.profile()["recur"]["launches"]
-                # fused while the pass covers at most 32 vectors: iteration 0 has none (cuda_compat: 0..2), then
-                # iterations up to k = 32 (34) ride with the dot products, the rest launch k_recur again
-                assert launches == (40 if fuse == "0" else 1 + 7 if reorth != "cuda_compat" else 3 + 5)
-        assert runs["1"][0].tobytes() == runs["0"][0].tobytes() and runs["1"][1].tobytes() == runs["0"][1].tobytes()
+                # iteration 0 has no pass (cuda_compat: 0..2); with the limit of 32, iterations up to k = 32 (34) ride
+                # with the dot products and the rest launch k_recur again
+                first = 3 if reorth == "cuda_compat" else 1
+                assert launches == {"0": 40, "1": first + (5 if reorth == "cuda_compat" else 7), "short": first}[fuse]
+        assert all(runs[f][0].tobytes() == runs["0"][0].tobytes() and runs[f][1].tobytes() == runs["0"][1].tobytes()
+                   for f in ("1", "short"))
         o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 41, 0.0,
                                "cuda_compat" if reorth == "cuda_compat" else "full")
         assert rel_err(la.ritz_values(*runs["1"], 40, 4), o.eigenvalues) < 1e-10
