@@ -60,6 +60,7 @@ struct Engine {
     int max_blocks = 0;    // 8 workgroups per CU, multiple of 8
     // what the matrix upload took (host arrays page-locked around the copies unless LANCZOS_HIP_PIN_UPLOAD=0)
     double upload_sec = 0.0, upload_bytes = 0.0;
+    double create_sec[4] = {0.0, 0.0, 0.0, 0.0};  // device set-up, upload, choice of the SpMV form (with its tables), state
     bool upload_pinned = false;
     char upload_pin_note[48] = "";  // "ok", "off", or the error the registration was refused with
     // device memory

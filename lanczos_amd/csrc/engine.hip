@@ -173,10 +173,21 @@ int Engine::create(Engine **out, int64_t n, int64_t nnz, const int64_t *rp, cons
     if (bad) return fail("lanczos_hip_create: column index out of range [0, %lld)", (long long)n_ext);
 
     Engine *e = new Engine();
+    using clk = std::chrono::steady_clock;
+    auto t0 = clk::now();
+    auto lap = [&](int i) {
+        const auto t1 = clk::now();
+        e->create_sec[i] = std::chrono::duration<double>(t1 - t0).count();
+        t0 = t1;
+    };
     int rc = e->setup_device(opt, n, n_ext, nnz, max_iter);
+    lap(0);
     if (rc == 0) rc = e->upload_crs(rp, ci, va);
+    lap(1);
     if (rc == 0) rc = e->choose_spmv(opt.spmv_kernel);
+    lap(2);
     if (rc == 0) rc = e->alloc_state();
+    lap(3);
     if (rc != 0) {
         delete e;
         return rc;

@@ -103,6 +103,7 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     const int ckpt_every = env_int("LANCZOS_HIP_CHECKPOINT_EVERY", 0);
     const char *resume_path = getenv("LANCZOS_HIP_RESUME");
 
+    const double t_create = now_sec();
     if (mat && (ngpu > 1 || loopback || force_slabs)) {
         if ((resume_path && *resume_path) || (ckpt_path && *ckpt_path && ckpt_every > 0) || want_vectors) {
             lz::fail("LANCZOS_HIP_NGPU: checkpoints and eigenvectors need the whole basis on one GPU");
@@ -174,6 +175,9 @@ int solve(const Mat_Crs *mat, lanczos_hip_matvec_fn *op, const void *op_mat, siz
     time_init = now_sec() - t_start;
     fprintf(stderr, "[INIT] name=upload sec=%.6f bytes=%.0f GBps=%.2f pinned=%d detail_ref=%s\n", e->upload_sec, e->upload_bytes,
             e->upload_sec > 0 ? e->upload_bytes / e->upload_sec / 1e9 : 0.0, (int)e->upload_pinned, e->upload_pin_note);
+    if (env_int("LANCZOS_HIP_INIT_TRACE", 0))  // where the set-up went: the engine's four stages, then the rest (start vector, events)
+        fprintf(stderr, "[INIT] name=stages device=%.6f upload=%.6f spmv_form=%.6f state=%.6f before_create=%.6f\n", e->create_sec[0],
+                e->create_sec[1], e->create_sec[2], e->create_sec[3], t_create - t_start);
     fprintf(stderr, "[INIT] name=total_wall sec=%.6f\n", time_init);
     fprintf(stderr, "[INIT] name=spmv_kernel detail_ref=%s\n", e->spmv_name);
 
