@@ -693,6 +693,19 @@ def test_checkpoint_resume_is_bitwise(gpu, tmp_path, reorth):
             e.checkpoint_load(path)
 
 
+def test_basis_that_does_not_fit_the_gpu_is_refused_cleanly(gpu):
+    """A basis of 4 TB: creation fails with the runtime's message, and the next engine works."""
+    a = la.synth_laplacian(3, 64)
+    with pytest.raises(la.LanczosHipError, match="(?i)memory"):
+        la.Engine(a, 2_000_000, reorth="full")
+    v0 = la.gaussian_fill(5, 0, a.dimension)
+    with la.Engine(a, 11, reorth="full") as e:
+        e.set_start(v0)
+        alpha, beta = e.run(10)
+    o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 2, 11, 0.0)
+    assert rel_err(alpha, o.alpha[:10]) < 1e-12
+
+
 def run_dropin(a, nth, max_iter, threshold, env=None):
     """lanczos_hip_crs() in a child process so that its stdout/stderr can be read."""
     code = (
