@@ -121,7 +121,12 @@ struct BlockEngine {
         profile = profile_;
         const int cus = base->cus;
         groups_spmm = cus * 8;
-        groups_update = cus * 4;
+        // Two workgroups a CU for the kernels that write W: any mix of reads and writes runs at 5.2-5.4 TB/s on this chip
+        // whatever the kernel's shape (scripts/probe/mix_probe.hip), and fewer, longer streams sit at the upper end
+        // (256^3, ms per launch at 1 / 2 / 3 / 4 / 8 a CU: update 2.25 / 2.05 / 2.10 / 2.13 / 2.13, scaling 0.85 / 0.81 / 0.82 / 0.85 / 0.85).
+        groups_update = cus * 2;
+        if (const char *g = getenv("LANCZOS_HIP_BLOCK_UPDATE_GROUPS"))
+            if (atoi(g) >= 1 && atoi(g) <= 8 && atoi(g) <= 2 * (max_steps + 1)) groups_update = cus * atoi(g);
         groups_gram = cus * 2;
         const int64_t tiles4 = (n_pad / kTileRows + 3) / 4;
         groups_update = (int)std::min<int64_t>(groups_update, tiles4);
