@@ -47,7 +47,9 @@ struct BlockEngine {
     int64_t hstride = 0;
     int groups_gram = 0, groups_update = 0, groups_spmm = 0;
     double *d_H = nullptr;      // [max_steps + 1][256]
-    double *d_small = nullptr;  // G, Rinv, R1, R2: 4 x 256
+    double *d_small = nullptr;  // G, Rinv, R1, R2, Rinv of the second factorisation: 5 x 256
+    double *d_Hc = nullptr;     // the three-term part's coefficients of the current step: 2 x 256
+    bool fold_passes = true;
     double *d_TA = nullptr, *d_TB = nullptr;
     int *d_status = nullptr;
     int *d_med_rows = nullptr, *d_long_rows = nullptr;  // rows over kMedRow / over kLongRow entries
@@ -76,6 +78,7 @@ struct BlockEngine {
         (void)hipFree(d_hpart);
         (void)hipFree(d_H);
         (void)hipFree(d_small);
+        (void)hipFree(d_Hc);
         (void)hipFree(d_TA);
         (void)hipFree(d_TB);
         (void)hipFree(d_status);
@@ -137,7 +140,9 @@ struct BlockEngine {
         HIP_TRY(hipMemsetAsync(d_Q, 0, qbytes, stream()));
         HIP_TRY(hipMalloc(&d_hpart, sizeof(double) * (size_t)groups_gram * (size_t)hstride));
         HIP_TRY(hipMalloc(&d_H, sizeof(double) * (size_t)hstride));
-        HIP_TRY(hipMalloc(&d_small, sizeof(double) * 4 * 256));
+        HIP_TRY(hipMalloc(&d_small, sizeof(double) * 5 * 256));
+        HIP_TRY(hipMalloc(&d_Hc, sizeof(double) * 2 * 256));
+        if (const char *f = getenv("LANCZOS_HIP_BLOCK_FUSE")) fold_passes = atoi(f) != 0;  // 0: the three-term part and the first scaling as passes of their own that write the block
         HIP_TRY(hipMalloc(&d_TA, sizeof(double) * 256 * (size_t)max_steps));
         HIP_TRY(hipMalloc(&d_TB, sizeof(double) * 256 * (size_t)max_steps));
         HIP_TRY(hipMalloc(&d_status, sizeof(int) * 4));
@@ -256,6 +261,47 @@ struct BlockEngine {
         return 0;
     }
 
+    // Hout[t - t0] = Q_t^T W' for W' = W - sum_{c0 <= c < c1} Q_c Hc[c - c0], W' never stored (c1 - c0 <= 2)
+    int gram_corrected(int t0, int t1, const double *W, double *Hout, int c0, int c1, const double *Hc) {
+        const int nb = t1 - t0;
+        {
+            // W once per segment; the correction's blocks are among the blocks of the first segment's products (their second
+            // read there comes from L2 and is not charged) and are read again by every further segment
+            const int segs = (nb + kGramSeg - 1) / kGramSeg;
+            Scope ps(this, LANCZOS_HIP_BK_GRAM, 8.0 * kW * (double)n * (nb + segs + (segs - 1) * (c1 - c0)));
+            hipLaunchKernelGGL(k_gram16_corr, dim3(groups_gram), dim3(kThreads), 0, stream(), (const double *)d_Q,
+                               blk_stride, t0, t1, W, n_pad, d_hpart, hstride, c0, c1, Hc);
+        }
+        {
+            const int count = nb * 256;
+            Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * (double)count * groups_gram);
+            hipLaunchKernelGGL(k_gram_reduce, dim3((count + kThreads - 1) / kThreads), dim3(kThreads), 0, stream(),
+                               (const double *)d_hpart, groups_gram, hstride, count, Hout);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
+    // The three-term part of step j, from d_H = [Q_ta Q_j]^T W: T's diagonal block, and the coefficients kept in d_Hc
+    // for the pass that applies them together with the full pass's.
+    int keep_three_term(int ta, int j) {
+        Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 512 * 2);
+        hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, stream(), (const double *)(d_H + (j - ta) * 256),
+                           d_TA + (size_t)j * 256);
+        HIP_TRY(hipMemcpyAsync(d_Hc, d_H, sizeof(double) * 256 * (size_t)(j + 1 - ta), hipMemcpyDeviceToDevice, stream()));
+        return 0;
+    }
+
+    // d_H[ta .. j] += d_Hc: W - Q (H + Hc) is then both parts in one update
+    int add_three_term(int ta, int j) {
+        const int count = 256 * (j + 1 - ta);
+        Scope ps(this, LANCZOS_HIP_BK_SMALL, 24.0 * count);
+        hipLaunchKernelGGL(k_add_coeff, dim3((count + kThreads - 1) / kThreads), dim3(kThreads), 0, stream(),
+                           d_H + (size_t)ta * 256, (const double *)d_Hc, count);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
+
     // W -= sum_t Q_t H_t; with gram_out the kernel also leaves W^T W of the result there (no extra pass)
     int update(int t0, int t1, double *W, const double *H, double *gram_out) {
         {
@@ -269,9 +315,10 @@ struct BlockEngine {
     }
 
     // G = sum over the update / scale workgroups' parts (one 16 x 16 block, fragment order in)
-    void reduce_own_gram(double *G) {
-        Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * groups_update);
-        hipLaunchKernelGGL(k_gram_reduce, dim3(1), dim3(kThreads), 0, stream(), (const double *)d_hpart, groups_update,
+    void reduce_own_gram(double *G, int groups = 0) {
+        if (groups == 0) groups = groups_update;
+        Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * groups);
+        hipLaunchKernelGGL(k_gram_reduce, dim3(1), dim3(kThreads), 0, stream(), (const double *)d_hpart, groups,
                            (int64_t)256, 256, G);
     }
 
@@ -289,20 +336,33 @@ struct BlockEngine {
     // slabs when the rows are partitioned): factorise, scale this engine's rows; the first pass leaves the Gram
     // matrix of ITS rows' result in d_small for the second.
     void chol_pass(int pass, int t, double *Bout) {
-        double *G = d_small, *Rinv = d_small + 256, *R1 = d_small + 512, *R2 = d_small + 768;
+        double *G = d_small, *Rinv = d_small + 256, *R1 = d_small + 512, *R2 = d_small + 768, *Rinv2 = d_small + 1024;
         {
             Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 256 * 3);
-            hipLaunchKernelGGL(k_chol16, dim3(1), dim3(kThreads), 0, stream(), (const double *)G, Rinv,
-                               pass == 0 ? R1 : R2, pass == 0 ? (const double *)nullptr : (const double *)R1,
+            hipLaunchKernelGGL(k_chol16, dim3(1), dim3(kThreads), 0, stream(), (const double *)G,
+                               pass == 1 && fold_passes ? Rinv2 : Rinv, pass == 0 ? R1 : R2,
+                               pass == 0 ? (const double *)nullptr : (const double *)R1,
                                pass == 0 ? (double *)nullptr : Bout, d_status, t + 1);
         }
-        {
+        if (fold_passes) {
+            // the block is not written between the two factorisations: the first pass only reads it (the Gram matrix of
+            // W Rinv1, formed in registers), the second writes (W Rinv1) Rinv2 -- the same bits as two scalings
+            if (pass == 0) {
+                Scope ps(this, LANCZOS_HIP_BK_SCALE, 8.0 * kW * (double)n);
+                hipLaunchKernelGGL(k_bscale16_gram, dim3(groups_gram), dim3(kThreads), 0, stream(), (const double *)slot(t),
+                                   n_pad, (const double *)Rinv, d_hpart);
+            } else {
+                Scope ps(this, LANCZOS_HIP_BK_SCALE, 2.0 * 8.0 * kW * (double)n);
+                hipLaunchKernelGGL(k_bscale16_chain, dim3(groups_update), dim3(kThreads), 0, stream(), slot(t), n_pad,
+                                   (const double *)Rinv, (const double *)Rinv2);
+            }
+        } else {
             Scope ps(this, LANCZOS_HIP_BK_SCALE, 2.0 * 8.0 * kW * (double)n);
             // the first scaling leaves the Gram matrix of its result for the second factorisation
             hipLaunchKernelGGL(k_bscale16, dim3(groups_update), dim3(kThreads), 0, stream(), slot(t), n_pad,
                                (const double *)Rinv, pass == 0 ? d_hpart : (double *)nullptr);
         }
-        if (pass == 0) reduce_own_gram(G);
+        if (pass == 0) reduce_own_gram(G, fold_passes ? groups_gram : groups_update);
     }
 
     int set_start(const double *x0_host) {
@@ -335,13 +395,21 @@ struct BlockEngine {
         if (int rc = spmm(slot(j), W)) return rc;
         const int ta = std::max(j - 1, 0);
         if (int rc = gram(ta, j + 1, W, d_H)) return rc;
-        {
-            Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 512);
-            hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, stream(), (const double *)(d_H + (j - ta) * 256),
-                               d_TA + (size_t)j * 256);
+        if (fold_passes) {
+            // the three-term part is not written out: the full pass's products are taken of W less that part, formed in
+            // registers, and one update applies both sets of coefficients
+            if (int rc = keep_three_term(ta, j)) return rc;
+            if (int rc = gram_corrected(0, j + 1, W, d_H, ta, j + 1, d_Hc)) return rc;
+            if (int rc = add_three_term(ta, j)) return rc;
+        } else {
+            {
+                Scope ps(this, LANCZOS_HIP_BK_SMALL, 8.0 * 512);
+                hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, stream(), (const double *)(d_H + (j - ta) * 256),
+                                   d_TA + (size_t)j * 256);
+            }
+            if (int rc = update(ta, j + 1, W, d_H, nullptr)) return rc;
+            if (int rc = gram(0, j + 1, W, d_H)) return rc;
         }
-        if (int rc = update(ta, j + 1, W, d_H, nullptr)) return rc;
-        if (int rc = gram(0, j + 1, W, d_H)) return rc;
         if (int rc = update(0, j + 1, W, d_H, d_small)) return rc;
         if (int rc = cholqr2(j + 1, d_TB + (size_t)j * 256, true)) return rc;
         steps += 1;
@@ -538,15 +606,22 @@ struct BlockMulti {
         for (int p = 0; p < P; ++p) {
             if (int rc = use(p)) return rc;
             BlockEngine *b = eng[(size_t)p];
-            hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, b->stream(), (const double *)(b->d_H + (j - ta) * 256),
-                               b->d_TA + (size_t)j * 256);
-            if (int rc = b->update(ta, j + 1, b->slot(j + 1), b->d_H, nullptr)) return rc;
-            if (int rc = b->gram(0, j + 1, b->slot(j + 1), b->d_H)) return rc;
+            if (b->fold_passes) {
+                if (int rc = b->keep_three_term(ta, j)) return rc;
+                if (int rc = b->gram_corrected(0, j + 1, b->slot(j + 1), b->d_H, ta, j + 1, b->d_Hc)) return rc;
+            } else {
+                hipLaunchKernelGGL(k_symm16, dim3(1), dim3(kThreads), 0, b->stream(), (const double *)(b->d_H + (j - ta) * 256),
+                                   b->d_TA + (size_t)j * 256);
+                if (int rc = b->update(ta, j + 1, b->slot(j + 1), b->d_H, nullptr)) return rc;
+                if (int rc = b->gram(0, j + 1, b->slot(j + 1), b->d_H)) return rc;
+            }
         }
         if (int rc = reduce(bufH, (size_t)(j + 1) * 256)) return rc;
         for (int p = 0; p < P; ++p) {
             if (int rc = use(p)) return rc;
             BlockEngine *b = eng[(size_t)p];
+            if (b->fold_passes)
+                if (int rc = b->add_three_term(ta, j)) return rc;
             if (int rc = b->update(0, j + 1, b->slot(j + 1), b->d_H, b->d_small)) return rc;
         }
         const size_t tb = (size_t)j * 256;

@@ -21,6 +21,7 @@ constexpr int kW = 16;          // block width
 constexpr int kThreads = 256;   // 4 wavefronts
 constexpr int kTileRows = 32;   // rows of a wavefront's tile in the contraction kernels
 constexpr int kGramSeg = 8;     // basis blocks whose accumulators a wavefront holds at once
+constexpr int kLdsRow = 17;  // doubles per LDS tile row (16 + 1 against bank conflicts)
 
 typedef double d4v __attribute__((ext_vector_type(4)));
 
@@ -277,6 +278,91 @@ k_gram16(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, const
     }
 }
 
+// The same for W' = W - sum_{c0 <= c < c1} Q_c Hc[c - c0] (c1 - c0 <= 2), with W' formed tile by tile in registers
+// and never stored: the three-term part of a block step then costs no pass that writes W (a launch that writes
+// runs at 5.3 TB/s on this chip, one that only reads at 6.8), its coefficients are added to those of the full pass
+// and one update applies both.  The correction is the update kernel's arithmetic (Q_c's tile through the
+// wavefront's LDS tile into the A operand); its result registers are rows 4r..4r+3 of the tile in the layout the
+// B operand of Q_t^T W' wants.
+__global__ void __launch_bounds__(kThreads)
+k_gram16_corr(const double *__restrict__ Q, int64_t blk_stride, int t0, int t1, const double *__restrict__ W,
+              int64_t n_pad, double *__restrict__ hpart, int64_t hstride, int c0, int c1,
+              const double *__restrict__ Hc) {
+    __shared__ double red[4][256];
+    __shared__ double lds[4][kTileRows * kLdsRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double *lt = lds[wave];
+    const int64_t tiles = n_pad / kTileRows;
+    double hb[2][4];  // minus the correction's coefficient blocks in B-operand layout
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) hb[c][s] = c0 + c < c1 ? -Hc[c * 256 + (4 * s + kk) * kW + cc] : 0.0;
+    for (int s0 = t0; s0 < t1; s0 += kGramSeg) {
+        const int ns = min(kGramSeg, t1 - s0);
+        d4v acc[kGramSeg];
+#pragma unroll
+        for (int t = 0; t < kGramSeg; ++t) acc[t] = d4v{0.0, 0.0, 0.0, 0.0};
+        for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+            const int64_t off = (tile * kTileRows + kk) * kW + cc;
+            d4v w2[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) w2[sub][r] = W[off + (sub * 16 + 4 * r) * kW];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (c0 + c < c1) {
+                    const double *q = Q + (int64_t)(c0 + c) * blk_stride + off;
+                    double x[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = q[u * 64];  // plain loads: the Gram part below reads the tile again
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) lt[(4 * u + kk) * kLdsRow + cc] = x[u];
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            w2[sub] = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], hb[c][s], w2[sub]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < kGramSeg; ++t) {
+                if (t < ns) {
+                    const double *q = Q + (int64_t)(s0 + t) * blk_stride + off;
+                    double a[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a[u] = ld_nt(q + u * 64);
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) acc[t] = mfma16(a[u], w2[u >> 2][u & 3], acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kGramSeg; ++t) {
+            if (t < ns) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave][r * 64 + lane] = acc[t][r];
+                __syncthreads();
+                const int e = threadIdx.x;
+                hpart[(int64_t)blockIdx.x * hstride + (int64_t)(s0 + t - t0) * 256 + e] =
+                    (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+            }
+        }
+    }
+}
+
+// H[i] += Hc[i], i < count (the three-term coefficients onto those of the full pass)
+__global__ void __launch_bounds__(kThreads)
+k_add_coeff(double *__restrict__ H, const double *__restrict__ Hc, int count) {
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i < count) H[i] += Hc[i];
+}
+
 // H[t][i][j] (row-major 16 x 16 per block) = sum over workgroups, in workgroup order
 __global__ void __launch_bounds__(kThreads)
 k_gram_reduce(const double *__restrict__ hpart, int groups, int64_t hstride, int count, double *__restrict__ H) {
@@ -298,7 +384,6 @@ k_gram_reduce(const double *__restrict__ hpart, int groups, int64_t hstride, int
 // The LDS tile is private to a wavefront, whose LDS operations execute in
 // order: no workgroup barrier is needed.
 // ---------------------------------------------------------------------------
-constexpr int kLdsRow = 17;  // doubles per LDS tile row (16 + 1 against bank conflicts)
 
 // gpart[wg][e] = the workgroup's sum of its four wavefronts' accumulators, fragment order
 // (e = 64 r + lane), added in wavefront order.  `scratch` is >= 1024 doubles of LDS no longer in use.
@@ -403,6 +488,90 @@ k_bscale16(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M, 
         }
     }
     if (gpart) emit_gram_part(gacc, reinterpret_cast<double *>(lds), gpart);
+}
+
+// CholQR twice without writing the block in between.  k_bscale16_gram: gpart = the workgroup's part of
+// (W M1)^T (W M1), W M1 formed tile by tile in registers and not stored (a launch that only reads).
+// k_bscale16_chain: W <- (W M1) M2, the first product formed exactly as the other kernel formed it, handed to the
+// second through the wavefront's LDS tile: bit for bit what k_bscale16 with M1 followed by k_bscale16 with M2
+// leaves, with one pass that writes instead of two.
+__global__ void __launch_bounds__(kThreads)
+k_bscale16_gram(const double *__restrict__ W, int64_t n_pad, const double *__restrict__ M1, double *__restrict__ gpart) {
+    __shared__ double lds[4][kTileRows * kLdsRow];
+    d4v gacc = d4v{0.0, 0.0, 0.0, 0.0};
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double *lt = lds[wave];
+    double mb[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) mb[s] = M1[(4 * s + kk) * kW + cc];
+    const int64_t tiles = n_pad / kTileRows;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t off = (tile * kTileRows + kk) * kW + cc;
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = W[off + u * 64];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lt[(4 * u + kk) * kLdsRow + cc] = x[u];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            d4v acc = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], mb[s], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gacc = mfma16(acc[r], acc[r], gacc);
+        }
+    }
+    emit_gram_part(gacc, reinterpret_cast<double *>(lds), gpart);
+}
+
+__global__ void __launch_bounds__(kThreads)
+k_bscale16_chain(double *__restrict__ W, int64_t n_pad, const double *__restrict__ M1, const double *__restrict__ M2) {
+    __shared__ double lds[4][kTileRows * kLdsRow];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kk = lane >> 4, cc = lane & 15;
+    double *lt = lds[wave];
+    double m1[4], m2[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        m1[s] = M1[(4 * s + kk) * kW + cc];
+        m2[s] = M2[(4 * s + kk) * kW + cc];
+    }
+    const int64_t tiles = n_pad / kTileRows;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < tiles; tile += (int64_t)gridDim.x * 4) {
+        const int64_t off = (tile * kTileRows + kk) * kW + cc;
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = W[off + u * 64];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) lt[(4 * u + kk) * kLdsRow + cc] = x[u];
+        __builtin_amdgcn_wave_barrier();
+        d4v first[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            first[sub] = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) first[sub] = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], m1[s], first[sub]);
+        }
+        // a result register is rows 4r..4r+3 of its half of the tile, the layout the tile was loaded in
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lt[(4 * (4 * sub + r) + kk) * kLdsRow + cc] = first[sub][r];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            d4v acc = d4v{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = mfma16(lt[(sub * 16 + cc) * kLdsRow + 4 * s + kk], m2[s], acc);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) W[off + (sub * 16 + 4 * r) * kW] = acc[r];
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------

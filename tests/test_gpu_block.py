@@ -113,6 +113,28 @@ def test_block_run_on_a_power_law_graph_laplacian(gpu):
     assert rel_err(got[:3], la.ritz_values(alpha, beta, 120, 3)) < 1e-10
 
 
+def test_three_term_part_folded_into_the_full_pass_is_the_same_iteration(gpu, monkeypatch):
+    """By default the three-term part of a block step is not written out (the full pass's products are taken of W
+    less that part, formed in registers; one update applies both sets of coefficients); LANCZOS_HIP_BLOCK_FUSE=0
+    runs it as a pass of its own.  Twelve steps (two segments of basis blocks in the Gram kernel): the same T,
+    the same basis, to rounding."""
+    a = la.synth_laplacian(3, 24)
+    x0 = start_block(a.dimension, 4)
+    out = {}
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("LANCZOS_HIP_BLOCK_FUSE", fuse)
+        with la.BlockEngine(a, 12) as e:
+            e.set_start(x0)
+            e.run(12)
+            out[fuse] = (e.tmatrix(), e.ritz(6), e.get_block(12))
+    (ta0, tb0), r0, q0 = out["0"]
+    (ta1, tb1), r1, q1 = out["1"]
+    assert np.max(np.abs(ta0 - ta1)) < 1e-12 * np.max(np.abs(ta0)) and np.max(np.abs(tb0 - tb1)) < 1e-12 * np.max(np.abs(ta0))
+    assert rel_err(r1, r0) < 1e-12
+    assert np.max(np.abs(q0 - q1)) < 1e-9
+    assert np.max(np.abs(q1.T @ q1 - np.eye(W))) < 1e-12
+
+
 @pytest.mark.parametrize("n,nblocks", [(16, 1), (4000, 3), (33333, 11), (70001, 20)])
 def test_projection_kernels_match_numpy(gpu, n, nblocks):
     """H = Q^T W and W -= Q H on arbitrary (non-orthogonal) data: checks the MFMA operand maps."""
