@@ -304,8 +304,35 @@ def big_laplacian_section(la, torch, N: int, steps: int = 100) -> dict:
         e.run(steps)
         prof = e.profile()
         name = e.spmv_name
-    fmt_iter = prof["spmv"]["bytes"] / steps + 32.0 * n   # the format's SpMV bytes + the recurrence's 32 n
+        # the same steps as the product followed by the recurrence kernel (50 bytes a row moved where the two plane
+        # walks of the default move 36)
+        os.environ["LANCZOS_HIP_TWO_PASS"] = "0"
+        try:
+            e.profile_select(())
+            e.set_start_seed(123456789)
+            e.run(5)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e.run(steps)
+            torch.cuda.synchronize()
+            dt_unfused = time.perf_counter() - t0
+            e.profile_select(None)
+            e.profile_reset()
+            e.run(steps)
+            prof_unfused = e.profile()
+        finally:
+            os.environ.pop("LANCZOS_HIP_TWO_PASS", None)
+    # bytes moved per iteration: what the product's and the recurrence's launches were charged (the format's SpMV bytes
+    # + the recurrence's 32 n; with the recurrence in the second plane walk's epilogue 10 n + 26 n)
+    fmt_iter = (prof["spmv"]["bytes"] + prof["recur"]["bytes"]) / steps
+    unfused_iter = (prof_unfused["spmv"]["bytes"] + prof_unfused["recur"]["bytes"]) / steps
     return {
+        "product_then_recurrence": {
+            "iters_per_s": steps / dt_unfused,
+            "bytes_moved_per_iter": unfused_iter,
+            "frac_of_hbm_peak": unfused_iter * steps / dt_unfused / 1e9 / HBM_PEAK_GBPS,
+            "kernel_ms_per_iter": {k: v["ms"] / steps for k, v in prof_unfused.items()},
+        },
         "workload": f"3-D 7-point Laplacian {N}^3 (n={n}, nnz={nnz}), SpMV + vector step, reorth=none",
         "steps": steps,
         "iters_per_s": steps / dt,
@@ -396,9 +423,19 @@ def single_gpu(args, keeper=None) -> dict:
     # iteration whose bytes do not grow with k
     eng.close()
 
-    def vector_step(spmv_choice, plain_rows=False):
+    def vector_step(spmv_choice, plain_rows=False, two_pass=True):
         # plain_rows: the row-wise form on the CRS arrays as they are (by default it walks a grid's planes over a
         # dictionary of column offsets, with the values read from the CRS array); read by the engine at creation
+        # two_pass=False: the dictionary form's step as the product followed by the recurrence kernel (by default,
+        # from 128^3, it is two plane walks that move 36 bytes a row in place of 50); read by the engine per iteration
+        if not two_pass:
+            os.environ["LANCZOS_HIP_TWO_PASS"] = "0"
+        try:
+            return vector_step_run(spmv_choice, plain_rows)
+        finally:
+            os.environ.pop("LANCZOS_HIP_TWO_PASS", None)
+
+    def vector_step_run(spmv_choice, plain_rows):
         if plain_rows:
             os.environ["LANCZOS_HIP_ROWS_PLANES"] = "0"
         try:
@@ -432,15 +469,20 @@ def single_gpu(args, keeper=None) -> dict:
         # 4 (n + 1) + 16 n; CRS values + pattern numbers = 8 nnz + 4 (n + 1) + 2 n + 16 n; dictionary = 2 n + 16 n)
         # plus the 32 n of the deferred-normalisation recurrence (alpha's partials come out of the SpMV,
         # there is no scaling pass)
-        fmt_spmv = p2["spmv"]["bytes"] / S
-        moved = fmt_spmv + 32.0 * n
+        # (with the recurrence in the second plane walk's epilogue: 10 n for the first walk, 26 n for the second)
+        moved = (p2["spmv"]["bytes"] + p2["recur"]["bytes"]) / S
         spmv_gb = p2["spmv"]["bytes"] / (p2["spmv"]["ms"] * 1e-3) / 1e9
         plain_crs = not (name.startswith("dict") or (name.startswith("rows") and name.endswith("p")))
+        two_walks = abs(p2["recur"]["bytes"] / S - 26.0 * n) < 1.0
         rec = {
             "iters_per_s": S / dt2,
             "ms_per_iter": dt2 / S * 1e3,
             "iters_per_s_with_every_kernel_timed": S / dt2_events,
             "spmv_kernel": name,
+            # two walks: class "spmv" below is the first walk (u . A u, reads 10 n), class "recur" the second
+            # (A u again with the recurrence in its epilogue, 26 n)
+            "step_form": "two plane walks: u.Au, then Au with the recurrence in its epilogue" if two_walks
+                         else "product, then the recurrence kernel",
             "matrix_format": "row-pattern dictionary" if name.startswith("dict") else
                              "CRS values and row offsets + column-offset patterns" if name.startswith("rows") and name.endswith("p")
                              else "CRS",
@@ -468,6 +510,11 @@ def single_gpu(args, keeper=None) -> dict:
         sv = sv_crs = {"spmv_kernel": spmv_name_main, "spmv_GBps": None}
     else:
         sv = vector_step(args.spmv)
+        if sv["spmv_kernel"].startswith("dict"):
+            unfused = vector_step(args.spmv, two_pass=False)
+            sv["product_then_recurrence"] = {k: unfused[k] for k in (
+                "iters_per_s", "ms_per_iter", "bytes_moved_per_iter", "achieved_GBps", "frac_of_hbm_peak", "spmv_avg_ms",
+                "spmv_GBps", "spmv_frac_of_hbm_peak", "kernel_ms_per_iter", "kernel_GBps")}
         # the same step on the plain CRS arrays (what the shared algorithmic-byte figure describes), and with the
         # column array replaced by pattern numbers (what a grid with variable coefficients runs on)
         if sv["spmv_kernel"].startswith("dict"):

@@ -425,6 +425,21 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
 // for the three positions of the ring are built once per workgroup; the step is instantiated per position.
 constexpr int kPlanesBlock = 512;
 
+// Sum of parts[0 .. count) over the workgroup, the same in every thread and on every run.
+template <int BLOCK>
+__device__ __forceinline__ double planes_sum_partials(const double *__restrict__ parts, int count, double *red) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += BLOCK) s += parts[i];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) t += red[w];
+    return t;
+}
+
 static size_t dict_planes_lds_bytes(int halo, int patterns, int stride, int span = kDictSpan) {
     return sizeof(double) * (size_t)(3 * (span + 2 * halo) + span) + (size_t)patterns * stride * (8 + 3 * 4) +
            sizeof(uint16_t) * span + 16;
@@ -441,16 +456,22 @@ static size_t dict_planes_lds_bytes(int halo, int patterns, int stride, int span
 // SPAN: rows of a plane per step, 1024 or 2048, two per thread.  A step loads SPAN + 2 halo doubles of x for SPAN rows:
 // the longer span re-reads less (512^3: 1.5 times x in place of 2), at the price of LDS (one workgroup of 1024
 // threads per CU where the short span has two or three of 512).
-template <int WPT, bool CRS_VALUES, int CACHE, int SPAN>
+// MODE: 0 the product (y and the partial sums of xdot . y); 1 the partial sums only, nothing written (a launch that
+// only reads); 2 the product with the recurrence in its epilogue: y never exists, what is written is
+// u_{k+1} = (s_k A u_k - c_p u_{k-1}) - c_k u_k, and the partial sums are those of ||u_{k+1}||^2.  1 then 2 make an
+// iteration without reorthogonalisation out of 36 bytes per row where the product followed by k_recur_lazy moves 50,
+// and out of one launch that writes where those are two.
+template <int WPT, bool CRS_VALUES, int CACHE, int SPAN, int MODE = 0>
 __global__ void __launch_bounds__(SPAN / 2)
 k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restrict__ rp, const double *__restrict__ val, const uint16_t *__restrict__ pattern, int patterns, int stride, int halo,
                    const int32_t *__restrict__ dlen, const int32_t *__restrict__ doff, const double *__restrict__ dval,
                    int far_a, int far_b, int plane_rows, int cols, int planes, int seg_len, int segs,
                    const double *__restrict__ x,
                    const double *__restrict__ xdot, double *__restrict__ y, double *__restrict__ partials,
-                   int64_t dot_lo, int64_t dot_hi) {
+                   int64_t dot_lo, int64_t dot_hi, DictRecur rc) {
     constexpr int BLOCK = SPAN / 2, ROWS = SPAN / BLOCK;
     static_assert(ROWS == 2, "two rows per thread");
+    static_assert(MODE == 0 || (!CRS_VALUES && CACHE == 0), "the recurrence rides with the plain dictionary form");
     extern __shared__ double win[];  // three windows | zeros | dictionary values | three index tables | patterns
     __shared__ double red[BLOCK / 64];
     const int tid = threadIdx.x;
@@ -495,6 +516,27 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
     const __amdgpu_buffer_rsrc_t rval =
         __builtin_amdgcn_make_buffer_rsrc((void *)val, 0, (int)(uint32_t)((uint64_t)nnz << 3), 0x00020000);
     double acc = 0.0;
+    double s_k = 1.0, c_p = 0.0, c_k = 0.0;  // MODE 2: the recurrence's scalars, as k_recur_lazy derives them
+    if constexpr (MODE == 2) {
+        const double dot = planes_sum_partials<BLOCK>(rc.dot_parts, rc.dot_count, red);
+        double beta_km1 = 0.0, s_km1 = 1.0;
+        if (rc.k > 0) {
+            beta_km1 = sqrt(planes_sum_partials<BLOCK>(rc.norm_parts, rc.norm_count, red));
+            s_k = 1.0 / beta_km1;
+            if (rc.k > 1) s_km1 = 1.0 / rc.beta_hist[rc.k - 2];
+        }
+        const double alpha = s_k * s_k * dot;
+        c_p = beta_km1 * s_km1;
+        c_k = alpha * s_k;
+        if (blockIdx.x == 0 && tid == 0) {
+            rc.alpha_hist[rc.k] = alpha;
+            if (rc.host_hist) rc.host_hist[2 * rc.k] = alpha;
+            if (rc.k > 0) {
+                rc.beta_hist[rc.k - 1] = beta_km1;
+                if (rc.host_hist) rc.host_hist[2 * (rc.k - 1) + 1] = beta_km1;
+            }
+        }
+    }
     if (live) {
         const int col = (int)(item % cols), seg = (int)(item / cols);
         const int zb = seg * seg_len, ze = min(zb + seg_len, planes);
@@ -560,6 +602,14 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
                 load_window(z + 2);
                 load_patterns(z + 1);
             }
+            double pv[ROWS];  // MODE 2: this thread's rows of u_{k-1}
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int u = 0; u < ROWS; ++u) {
+                    const int64_t r = row0 + u * BLOCK + tid;
+                    pv[u] = r < n ? __builtin_nontemporal_load(rc.uprev + r) : 0.0;
+                }
+            }
             __syncthreads();
             const int32_t *idx = s_idx + ROT * tab;
             int base[ROWS], len[ROWS];
@@ -622,13 +672,18 @@ k_spmv_dict_planes(int64_t n, int64_t n_ext, int64_t nnz, const int32_t *__restr
 #pragma unroll
             for (int u = 0; u < ROWS; ++u) {
                 const int64_t r = row0 + u * BLOCK + tid;
-                if (r < n && u * BLOCK + tid < lim) {
+                if constexpr (MODE == 2) {
+                    const double xk = win[ROT * wlen + halo + u * BLOCK + tid];
+                    sum[u] = (s_k * sum[u] - c_p * pv[u]) - c_k * xk;
+                    acc += (r < n && u * BLOCK + tid < lim) ? sum[u] * sum[u] : 0.0;
+                } else if (r < n && u * BLOCK + tid < lim) {
                     double xd = win[ROT * wlen + halo + u * BLOCK + tid];
                     if (xdot != x) xd = xdot[r];
                     const double t = xd * sum[u];
                     acc += (r >= dot_lo && r < dot_hi) ? t : 0.0;  // a select: a NaN in t goes no further
                 }
             }
+            if constexpr (MODE == 1) return;  // the sums were all this launch is for
             // lanes t and t ^ 1 pair their sums: the even lane stores rows (t, t + 1) of the first row set, the odd
             // lane those of the second
             const bool odd = tid & 1;
@@ -930,7 +985,7 @@ using DictAheadKernel = void (*)(int64_t, int64_t, const uint16_t *, int, int, i
                                  int64_t);
 using DictPlanesKernel = void (*)(int64_t, int64_t, int64_t, const int32_t *, const double *, const uint16_t *, int, int,
                                   int, const int32_t *, const int32_t *, const double *, int, int, int, int, int, int, int,
-                                  const double *, const double *, double *, double *, int64_t, int64_t);
+                                  const double *, const double *, double *, double *, int64_t, int64_t, DictRecur);
 
 // The plane walk's two knobs when the environment does not set them, from measurements on 256^3 and 512^3 (ms per SpMV,
 // span 1024 / 2048 x tables / registers): 256^3 0.0713 0.0784 | 0.0718 0.0772; 512^3 0.534 0.515 | 0.510 0.539.
@@ -994,13 +1049,17 @@ int Engine::launch_spmv_pdict(const double *x, const double *xdot, double *y, in
                        (const double *)d_val, (const uint16_t *)d_pattern, dict_patterns, dict_stride, dict_halo,
                        (const int32_t *)d_dlen, (const int32_t *)d_doff, (const double *)d_dval, (int)dict_plane_a,
                        (int)dict_plane_b, (int)dict_plane_f, cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials,
-                       (int64_t)0, n);
+                       (int64_t)0, n, DictRecur{});
     const hipError_t st = hipGetLastError();
     if (st != hipSuccess) return fail("lanczos_hip: %s", hipGetErrorString(st));
     return 0;
 }
 
-int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo, int64_t dot_hi) {
+// mode 0: y = A x and the partial sums of xdot . y in d_partials.  Modes 1 and 2 (the plane walk only, see
+// k_spmv_dict_planes): 1 the partial sums alone; 2 y = u_{k+1} by the recurrence in `recur`, the partial sums of its
+// squared norm in `parts_out`.
+int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo, int64_t dot_hi,
+                             int mode, const void *recur, double *parts_out) {
     if (dot_hi < 0) dot_hi = n;
     const int64_t chunks = (n + kDictSpan - 1) / kDictSpan;
     const int wlen = kDictSpan + 2 * dict_halo;
@@ -1028,11 +1087,13 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         const size_t lds = dict_planes_lds_bytes(dict_halo, dict_patterns, dict_stride, span);
         const int w = dict_window_per_thread(wlen_p, block);
 #define LZ_PLANES_C(W_, S_) \
-    (cache == 2 ? k_spmv_dict_planes<W_, false, 2, S_> : cache == 1 ? k_spmv_dict_planes<W_, false, 1, S_> : k_spmv_dict_planes<W_, false, 0, S_>)
+    (mode == 2 ? k_spmv_dict_planes<W_, false, 0, S_, 2> : mode == 1 ? k_spmv_dict_planes<W_, false, 0, S_, 1> : \
+     cache == 2 ? k_spmv_dict_planes<W_, false, 2, S_> : cache == 1 ? k_spmv_dict_planes<W_, false, 1, S_> : k_spmv_dict_planes<W_, false, 0, S_>)
 #define LZ_PLANES(W_) (span == 2048 ? LZ_PLANES_C(W_, 2048) : LZ_PLANES_C(W_, 1024))
         const DictPlanesKernel kernel = w <= 4 ? LZ_PLANES(4) : w <= 6 ? LZ_PLANES(6) : LZ_PLANES(10);
 #undef LZ_PLANES
 #undef LZ_PLANES_C
+        const DictRecur rc = recur ? *static_cast<const DictRecur *>(recur) : DictRecur{};
         if (dict_blocks == 0) {
             const int64_t want = std::min<int64_t>((int64_t)cus * dict_resident(kernel, block, lds), max_blocks);
             dict_segs = (int)std::max<int64_t>(1, std::min<int64_t>(planes / 3, want / cols));
@@ -1044,8 +1105,10 @@ int Engine::launch_spmv_dict(const double *x, const double *xdot, double *y, int
         hipLaunchKernelGGL(kernel, dim3(dict_blocks), dim3(block), lds, stream, n, n_ext, nnz,
                            (const int32_t *)nullptr, (const double *)nullptr, pat, dict_patterns, dict_stride, dict_halo,
                            dl, dof, dv, (int)dict_plane_a, (int)dict_plane_b, (int)dict_plane_f,
-                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, d_partials, dot_lo, dot_hi);
+                           cols, planes, dict_seg_len, dict_segs, x, xdot, y, mode == 2 ? parts_out : d_partials, dot_lo,
+                           dot_hi, rc);
     } else if (form == 1) {
+        if (mode != 0) return fail("lanczos_hip: the recurrence rides with the plane-walking form only");
         // loads one step ahead; 16-byte loads when no pair of doubles can straddle the start of x
         // (LANCZOS_HIP_DICT_WIDE=0: never); 512 threads, two rows per thread (LANCZOS_HIP_DICT_BLOCK=256: four)
         static const bool wide_env = !(getenv("LANCZOS_HIP_DICT_WIDE") && atoi(getenv("LANCZOS_HIP_DICT_WIDE")) == 0);

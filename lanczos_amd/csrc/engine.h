@@ -40,6 +40,19 @@ int guarded(const char *what, F &&body) noexcept {
     }
 }
 
+// What the plane walk needs to apply the deferred-normalisation recurrence (kernels.hip.h: k_recur_lazy) in its
+// epilogue: the vector before x, the iteration, the partial sums that hold x . A x and the previous ||u||^2, and where
+// alpha_k and beta_{k-1} are recorded.
+struct DictRecur {
+    const double *uprev;
+    int k;
+    const double *dot_parts;
+    int dot_count;
+    const double *norm_parts;
+    int norm_count;
+    double *alpha_hist, *beta_hist, *host_hist;
+};
+
 struct Engine {
     // geometry
     int64_t n = 0;         // local rows
@@ -172,7 +185,10 @@ struct Engine {
     int launch_spmv_pdict(const double *x, const double *xdot, double *y, int *nparts);
     int dict_form() const;
     void free_dict();
-    int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1);
+    int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1,
+                         int mode = 0, const void *recur = nullptr, double *parts_out = nullptr);
+    int enqueue_two_pass();          // an iteration without reorthogonalisation as two plane walks (dict.hip)
+    bool two_pass_ok();
     int build_panels(int bits);
     template <int RB, int T>
     int build_panels_shape(int bits, bool even);

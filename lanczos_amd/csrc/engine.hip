@@ -1107,10 +1107,46 @@ int Engine::launch_product(int kk) {
     return 0;
 }
 
+// An iteration without reorthogonalisation on a grid's dictionary form as two plane walks: the first only reads
+// and leaves the partial sums of u_k . A u_k, the second forms A u_k again and writes u_{k+1} by the
+// deferred-normalisation recurrence in its epilogue (dict.hip, MODE 1 and 2).  36 bytes per row in place of the
+// 50 of product + k_recur_lazy, and one launch that writes in place of two.  LANCZOS_HIP_TWO_PASS=0 / 1 forces
+// the choice (read per iteration: tests compare the two).
+bool Engine::two_pass_ok() {
+    if (!lazy || reorth != LANCZOS_HIP_REORTH_NONE || slab || ext_matvec || nnz == 0 ||
+        spmv_kind != LANCZOS_HIP_SPMV_DICT || dict_form() != 2)
+        return false;
+    const char *env = getenv("LANCZOS_HIP_TWO_PASS");
+    if (env && *env) return atoi(env) != 0;
+    // from 128^3: below, a step is the sum of its launches' fixed costs and the recurrence kernel is the lighter second launch
+    // (it/s, product + recurrence against two walks: 96^3 56 500 / 49 700, 128^3 36 900 / 38 700, 160^3 21 900 / 23 300,
+    // 256^3 7 100 / 7 950, 512^3 855 / 1 005)
+    return 8.0 * (double)n >= 16.0 * 1048576.0;
+}
+
+int Engine::enqueue_two_pass() {
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_SPMV, 10.0 * (double)n);  // pattern numbers and x
+        if (int rc = launch_spmv_dict(vec(k), vec(k), nullptr, &alpha_count, 0, -1, 1, nullptr, nullptr)) return rc;
+    }
+    {
+        ProfScope ps(this, LANCZOS_HIP_K_RECUR, 26.0 * (double)n);  // those, u_{k-1} read, u_{k+1} written
+        const DictRecur rc{k > 0 ? vec(k - 1) : vec(k), k, d_partials, alpha_count, norm_parts(k - 1), norm_count,
+                           d_alpha,            d_beta, h_hist};
+        int blocks = 0;
+        if (int r = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &blocks, 0, -1, 2, &rc, norm_parts(k))) return r;
+        norm_count = blocks;
+    }
+    k += 1;
+    if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
+    return 0;
+}
+
 // One whole iteration on a single GPU: the reductions' last stages are folded
 // into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
     if (int rc = check_can_step()) return rc;
+    if (two_pass_ok()) return enqueue_two_pass();
     if (spec_spmv_k != k)  // else: launched ahead by the previous iteration, on the vector that stood
         if (int rc = launch_product(k)) return rc;
     spec_spmv_k = -1;

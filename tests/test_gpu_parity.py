@@ -693,6 +693,36 @@ def test_checkpoint_resume_is_bitwise(gpu, tmp_path, reorth):
             e.checkpoint_load(path)
 
 
+def test_iteration_as_two_plane_walks_matches_product_then_recurrence(gpu, monkeypatch):
+    """Without reorthogonalisation a grid's dictionary form steps as two plane walks from 128^3 (the first leaves
+    u . A u and writes nothing, the second forms A u again and applies the deferred-normalisation recurrence in its
+    epilogue); LANCZOS_HIP_TWO_PASS forces either form at any size.  Same alpha/beta as the product followed by the
+    recurrence kernel, and as the CPU restatement; the run continues across a switch of form."""
+    for N in (64, 70, 90):
+        a = la.synth_laplacian(3, N)
+        v0 = la.gaussian_fill(3, 0, a.dimension)
+        out = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", mode)
+            with la.Engine(a, 61, reorth="none") as e:
+                assert e.spmv_name.endswith("p"), e.spmv_name
+                e.set_start(v0)
+                out[mode] = e.run(60)
+        assert rel_err(out["1"][0], out["0"][0]) < 1e-13 and rel_err(out["1"][1], out["0"][1]) < 1e-13
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 61, 0.0, reorth="none")
+        assert rel_err(out["1"][0][:25], o.alpha[:25]) < 1e-11 and rel_err(out["1"][1][:25], o.beta[:25]) < 1e-11
+        with la.Engine(a, 61, reorth="none") as e:
+            e.set_start(v0)
+            monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", "1")
+            a1, b1 = e.run(17)
+            monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", "0")
+            a2, b2 = e.run(20)
+            monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", "1")
+            a3, b3 = e.run(23)
+        assert rel_err(np.concatenate([a1, a2, a3]), out["0"][0]) < 1e-13
+        assert rel_err(np.concatenate([b1, b2, b3]), out["0"][1]) < 1e-13
+
+
 def test_basis_that_does_not_fit_the_gpu_is_refused_cleanly(gpu):
     """A basis of 4 TB: creation fails with the runtime's message, and the next engine works."""
     a = la.synth_laplacian(3, 64)
