@@ -189,6 +189,7 @@ struct Engine {
                          int mode = 0, const void *recur = nullptr, double *parts_out = nullptr);
     int enqueue_two_pass();          // an iteration without reorthogonalisation as two plane walks (dict.hip)
     bool two_pass_ok();
+    bool walk_pending = false;       // a row slab's iteration in progress runs as two plane walks
     int build_panels(int bits);
     template <int RB, int T>
     int build_panels_shape(int bits, bool even);

@@ -829,6 +829,12 @@ void Engine::reorth_range(int *l0, int *l1) const {
 int Engine::phase_spmv(double *red) {
     if (int rc = check_can_step()) return rc;
     const double *x = x_ext ? x_ext : vec(k);
+    walk_pending = lazy_slab && two_pass_ok();
+    if (walk_pending) {  // the first of two plane walks: u_k . A u_k, nothing written
+        ProfScope ps(this, LANCZOS_HIP_K_SPMV, 10.0 * (double)n);
+        if (int rc = launch_spmv_dict(vec(k), vec(k), nullptr, &alpha_count, 0, -1, 1, nullptr, nullptr)) return rc;
+        return finalize_spmv(red);
+    }
     if (int rc = launch_spmv(x, vec(k), vec(k + 1), &alpha_count)) return rc;
     return finalize_spmv(red);
 }
@@ -887,8 +893,13 @@ int Engine::phase_spmv_begin(int64_t b_lo, int64_t b_hi) {
         return fail("lanczos_hip_phase_spmv_begin: needs a caller-owned basis and the dictionary, rows, pipe, stream or "
                     "vector SpMV");
     if (b_lo < 0 || b_hi > n || b_lo > b_hi) return fail("lanczos_hip_phase_spmv_begin: bad row range");
-    ProfScope ps(this, LANCZOS_HIP_K_SPMV, spmv_bytes());
-    if (spmv_kind == LANCZOS_HIP_SPMV_DICT) {
+    walk_pending = lazy_slab && two_pass_ok();
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, walk_pending ? 10.0 * (double)n : spmv_bytes());
+    if (walk_pending) {
+        // the first of two plane walks: the partial sums of u_k . A u_k over the rows that read nothing remote, nothing
+        // written; phase_spmv_end adds the edge rows' share, phase_recur_lazy is the second walk
+        if (int rc = launch_spmv_dict(vec(k), vec(k), nullptr, &alpha_count, b_lo, b_hi, 1, nullptr, nullptr)) return rc;
+    } else if (spmv_kind == LANCZOS_HIP_SPMV_DICT) {
         // every row at once; the edge rows are done again later and do not count towards the dot product
         if (int rc = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &alpha_count, b_lo, b_hi)) return rc;
     } else {
@@ -948,6 +959,17 @@ int Engine::phase_spmv_end(double *red) {
 int Engine::phase_recur_lazy(double *red) {
     if (int rc = check_affinity(this, "phase_recur_lazy")) return rc;
     if (!lazy_slab) return fail("lanczos_hip_phase_recur_lazy: needs reorth=none on a row-partitioned engine");
+    if (walk_pending) {
+        // the second plane walk: A u_k again (the remote planes have arrived) with the recurrence in its epilogue
+        walk_pending = false;
+        ProfScope ps(this, LANCZOS_HIP_K_RECUR, 26.0 * (double)n);
+        const DictRecur rc{k > 0 ? vec(k - 1) : vec(k), k, red, 1, red + 1, 1, d_alpha, d_beta, h_hist};
+        int blocks = 0;
+        if (int r = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &blocks, 0, -1, 2, &rc, norm_parts(k))) return r;
+        norm_count = blocks;
+        k += 1;
+        return 0;
+    }
     const int blocks = recur_blocks();
     {
         ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
@@ -1113,7 +1135,8 @@ int Engine::launch_product(int kk) {
 // 50 of product + k_recur_lazy, and one launch that writes in place of two.  LANCZOS_HIP_TWO_PASS=0 / 1 forces
 // the choice (read per iteration: tests compare the two).
 bool Engine::two_pass_ok() {
-    if (!lazy || reorth != LANCZOS_HIP_REORTH_NONE || slab || ext_matvec || nnz == 0 ||
+    // one GPU, or a row slab stepping phase by phase (phase_spmv* takes the first walk, phase_recur_lazy the second)
+    if (!(lazy || lazy_slab) || reorth != LANCZOS_HIP_REORTH_NONE || x_ext || ext_matvec || nnz == 0 ||
         spmv_kind != LANCZOS_HIP_SPMV_DICT || dict_form() != 2)
         return false;
     const char *env = getenv("LANCZOS_HIP_TWO_PASS");
@@ -1121,7 +1144,11 @@ bool Engine::two_pass_ok() {
     // from 128^3: below, a step is the sum of its launches' fixed costs and the recurrence kernel is the lighter second launch
     // (it/s, product + recurrence against two walks: 96^3 56 500 / 49 700, 128^3 36 900 / 38 700, 160^3 21 900 / 23 300,
     // 256^3 7 100 / 7 950, 512^3 855 / 1 005)
-    return 8.0 * (double)n >= 16.0 * 1048576.0;
+    // and from about a hundred planes: every segment of a walk loads a plane before and a plane after its own, which two
+    // walks pay twice (slabs of a 512^3 grid, ms per step, two launches / two walks: 256 planes 0.592 / 0.538, 128 planes
+    // 0.306 / 0.301, 64 planes 0.165 / 0.167; of a 256^3 grid: 128 planes 0.0841 / 0.0802, 32 planes 0.0368 / 0.0385)
+    const int64_t planes = dict_plane_f > 0 ? (n + dict_plane_f - 1) / dict_plane_f : 0;
+    return 8.0 * (double)n >= 16.0 * 1048576.0 && planes >= 100;
 }
 
 int Engine::enqueue_two_pass() {
@@ -1146,7 +1173,7 @@ int Engine::enqueue_two_pass() {
 // into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
     if (int rc = check_can_step()) return rc;
-    if (two_pass_ok()) return enqueue_two_pass();
+    if (!slab && two_pass_ok()) return enqueue_two_pass();
     if (spec_spmv_k != k)  // else: launched ahead by the previous iteration, on the vector that stood
         if (int rc = launch_product(k)) return rc;
     spec_spmv_k = -1;

@@ -97,6 +97,28 @@ def test_two_ranks_on_one_gpu_match_one_engine(gpu, kind, mode, reorth, expect):
         assert kernel.startswith("panel")
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_step_as_two_plane_walks(gpu, monkeypatch, overlap):
+    """Without reorthogonalisation a slab of whole planes steps as two plane walks like one GPU does (from 2^21 rows by
+    default; forced here): the first walk beside the exchange, its edge rows' share added when the planes have arrived,
+    the second walk in place of the recurrence kernel.  Against one engine running product + recurrence kernel."""
+    monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", "1")      # inherited by the spawned ranks; the one engine they compare
+    if not overlap:                                       # with runs the two walks too (they match the kernels to 1e-13:
+        monkeypatch.setenv("LANCZOS_DIST_NO_OVERLAP", "1")  # tests/test_gpu_parity.py)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "lap3d48", "auto", "none", 30, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    chosen, ea, eb, kernel, overlapped = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert chosen == "halo" and overlapped == overlap and kernel.endswith("p")
+    assert ea < 1e-11 and eb < 1e-11, (ea, eb)
+
+
 @pytest.mark.parametrize("switch,reorth", [("LANCZOS_DIST_NO_INPLACE", "none"), ("LANCZOS_DIST_NO_INPLACE", "full"),
                                            ("LANCZOS_DIST_NO_OVERLAP", "full")])
 def test_two_ranks_with_the_other_exchange_forms(gpu, monkeypatch, switch, reorth):

@@ -59,17 +59,24 @@ def test_loopback_slabs_match_the_single_engine_and_the_oracle(gpu, reorth):
         assert rel_err(la.ritz_values(a2, b2, cmp, 4), o.eigenvalues) < 1e-10, (reorth, slabs)
 
 
+@pytest.mark.parametrize("walks", ["0", "1"])
 @pytest.mark.parametrize("span", ["1024", "2048"])
 @pytest.mark.parametrize("reorth", ["full", "none"])
-def test_loopback_slabs_of_whole_planes_walk_them(gpu, reorth, span, monkeypatch):
+def test_loopback_slabs_of_whole_planes_walk_them(gpu, reorth, span, walks, monkeypatch):
     """64^3 cut into 2 and 4 slabs of whole planes: every slab's dictionary SpMV walks its planes, with the
     neighbours' planes (received into the vectors' tails) as the plane before its first and after its last;
-    with 1024 and with 2048 rows of a plane per step (the form long grid lines take by default)."""
+    with 1024 and with 2048 rows of a plane per step (the form long grid lines take by default).  walks = 1: without
+    reorthogonalisation the slabs' iteration is two plane walks (large slabs' default), against product + recurrence
+    kernel on one engine."""
+    if walks == "1" and reorth != "none":
+        pytest.skip("the two walks are the iteration without reorthogonalisation")
     monkeypatch.setenv("LANCZOS_HIP_DICT_SPAN", span)
     a = la.synth_laplacian(3, 64)
     v0 = la.gaussian_fill(5, 0, a.dimension)
     steps = 30
+    monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", "0")
     a1, b1 = single(a, v0, steps, reorth)
+    monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", walks)
     for slabs in (2, 4):
         with la.MultiEngine(a, steps + 1, slabs, reorth=reorth, loopback=True) as m:
             assert m.info()["halo"] == 1
