@@ -717,15 +717,27 @@ int Engine::launch_dots(int l0, int l1, double *red_out) {
     for (int s0 = l0; s0 < l1; s0 += kMaxDotsSegment) {
         const int s1 = std::min(l1, s0 + kMaxDotsSegment);
         const int nl = s1 - s0;
+        // long vectors and more than the 32 vectors the fused sweep takes: k_dots_big (LANCZOS_HIP_DOTS_BIG=0 / 1
+        // forces the choice, read per launch)
+        constexpr int kBigP = 32;
+        const int64_t big_groups = (npad / 2) / kTileV2 / (kBigP / kEPT2);
+        const char *big_env = getenv("LANCZOS_HIP_DOTS_BIG");
+        const bool big = big_env && *big_env ? atoi(big_env) != 0 && big_groups >= 1 : big_groups >= 2 * (int64_t)cus && nl > 32;
+        const int grid = big ? (int)std::min<int64_t>(blocks, big_groups) : blocks;
         {
             ProfScope ps(this, LANCZOS_HIP_K_DOTS, 8.0 * (double)n * nl + 8.0 * (double)n);
-            hipLaunchKernelGGL(k_dots, dim3(blocks), dim3(kBlock), sizeof(double) * kWavesPerBlock * nl, stream,
-                               (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), npad / 2,
-                               d_hpart, hstride);
+            if (big)
+                hipLaunchKernelGGL(k_dots_big<kBigP>, dim3(grid), dim3(kBlock), sizeof(double) * kWavesPerBlock * nl, stream,
+                                   (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), npad / 2,
+                                   d_hpart, hstride);
+            else
+                hipLaunchKernelGGL(k_dots, dim3(grid), dim3(kBlock), sizeof(double) * kWavesPerBlock * nl, stream,
+                                   (const double2 *)d_V, ldv / 2, s0, s1, (const double2 *)vec(k + 1), npad / 2,
+                                   d_hpart, hstride);
         }
         {
-            ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (double)blocks * nl);
-            hipLaunchKernelGGL(k_hreduce, dim3(nl), dim3(kBlock), 0, stream, d_hpart, hstride, blocks,
+            ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * (double)grid * nl);
+            hipLaunchKernelGGL(k_hreduce, dim3(nl), dim3(kBlock), 0, stream, d_hpart, hstride, grid,
                                red_out + (s0 - l0));
         }
     }
@@ -757,11 +769,23 @@ int Engine::launch_recur_dots(const double *alpha_parts, int alpha_cnt, int l0, 
 }
 
 int Engine::launch_update(int l0, int l1, const double *h, int *nparts) {
-    const int blocks = tile_blocks();
-    *nparts = blocks;
+    int blocks = tile_blocks();
     ProfScope ps(this, LANCZOS_HIP_K_UPDATE, 8.0 * (double)n * (l1 - l0) + 16.0 * (double)n);
-    hipLaunchKernelGGL(k_update, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
-                       (double2 *)vec(k + 1), npad / 2, h, norm_parts(k));
+    // long vectors and a pass of some length: 128 KiB of every basis vector per workgroup at a time (k_update_big;
+    // LANCZOS_HIP_UPDATE_BIG=0 / 1 forces the choice, read per launch: tests compare the two)
+    constexpr int kBigP = 32;
+    const int64_t big_groups = (npad / 2) / kTileV2 / (kBigP / kEPT2);
+    const char *big_env = getenv("LANCZOS_HIP_UPDATE_BIG");
+    const bool big = big_env && *big_env ? atoi(big_env) != 0 && big_groups >= 1 : big_groups >= 2 * (int64_t)cus && l1 - l0 >= 8;
+    if (big) {
+        blocks = (int)std::min<int64_t>(blocks, std::max<int64_t>(big_groups, 1));
+        hipLaunchKernelGGL(k_update_big<kBigP>, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
+                           (double2 *)vec(k + 1), npad / 2, h, norm_parts(k));
+    } else {
+        hipLaunchKernelGGL(k_update, dim3(blocks), dim3(kBlock), 0, stream, (const double2 *)d_V, ldv / 2, l0, l1,
+                           (double2 *)vec(k + 1), npad / 2, h, norm_parts(k));
+    }
+    *nparts = blocks;
     norm_count = blocks;
     HIP_TRY(hipGetLastError());
     return 0;

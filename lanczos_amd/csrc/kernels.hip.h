@@ -1225,6 +1225,63 @@ k_dots(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, const double
         hpart[(size_t)j * hstride + blockIdx.x] = (hs[j] + hs[nl + j]) + (hs[2 * nl + j] + hs[3 * nl + j]);
 }
 
+// k_dots on long vectors, as k_update_big is to k_update: a workgroup holds P / kEPT2 consecutive tiles of w in
+// registers while the basis streams past, 128 KiB of every vector at a time; the tiles that do not fill such a group
+// are taken as k_dots takes them.  The products are the same; a wavefront's sums run over the group's pieces before
+// they are added up across lanes, so the coefficients agree with k_dots' to rounding, not bit for bit.
+template <int P>
+__global__ void __launch_bounds__(kBlock)
+k_dots_big(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, const double2 *__restrict__ w,
+           int64_t n2, double *__restrict__ hpart, int hstride) {
+    extern __shared__ double hs[];  // [4][nl]
+    const int nl = l1 - l0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < nl * kWavesPerBlock; j += kBlock) hs[j] = 0.0;
+    __syncthreads();
+    double *myhs = hs + wave * nl;
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    constexpr int G = P / kEPT2;
+    const int64_t groups = tiles / G;
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t base = g * (int64_t)(G * kTileV2) + threadIdx.x;
+        double2 wt[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            // eight running sums: one chain of 2 P dependent multiply-adds per vector would leave the loads waiting
+            double p[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            double2 q[P];  // all of the group's loads of this vector before the first product
+#pragma unroll
+            for (int u = 0; u < P; ++u) q[u] = ld_stream(vl + u * kBlock);
+#pragma unroll
+            for (int u = 0; u < P; ++u) p[u & 7] += q[u].x * wt[u].x + q[u].y * wt[u].y;
+            const double s = wave_sum(((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7])));
+            if (lane == 0) myhs[l] += s;
+        }
+    }
+    for (int64_t t = groups * G + blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 wt[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            double p = 0.0;
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                const double2 q = ld_stream(vl + u * kBlock);
+                p += q.x * wt[u].x + q.y * wt[u].y;
+            }
+            p = wave_sum(p);
+            if (lane == 0) myhs[l] += p;
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < nl; j += kBlock)
+        hpart[(size_t)j * hstride + blockIdx.x] = (hs[j] + hs[nl + j]) + (hs[2 * nl + j] + hs[3 * nl + j]);
+}
+
 // The three-term recurrence and the first half of the reorthogonalisation pass in one sweep: a workgroup
 // forms its tile of w <- (w - beta v_{k-1}) - alpha v_k (the expression of k_recur), writes it, and keeps it in
 // registers while V_{l0..l1-1} stream past it as in k_dots.  Same tiles, same grid and the same order of
@@ -1295,6 +1352,68 @@ k_update(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *_
         for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
         const double2 *vl = V + (int64_t)l0 * ldv2 + base;
 #pragma unroll 2
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            const double c = h[l];
+#pragma unroll
+            for (int u = 0; u < kEPT2; ++u) {
+                const double2 q = ld_stream(vl + u * kBlock);
+                wt[u].x -= q.x * c;
+                wt[u].y -= q.y * c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) {
+            st_stream(w + base + u * kBlock, wt[u]);
+            acc += wt[u].x * wt[u].x + wt[u].y * wt[u].y;
+        }
+    }
+    const double tsum = block_sum(acc, red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = tsum;
+}
+
+// k_update on long vectors: a workgroup owns P / kEPT2 consecutive tiles at a time (P = 32: 128 KiB of every basis
+// vector in one go), the tiles that do not fill such a group are taken as k_update takes them.  Every element of w
+// goes through the same subtractions in the same order as in k_update -- only the grouping of the w.w partial sums
+// differs.  Longer runs of consecutive addresses per workgroup and vector are what the basis stream wants: at
+// k = 150 on 2^24 rows 7.0 TB/s against 6.5 with 16 KiB tiles (32 and 64 KiB tiles reach that only at some grid
+// sizes and fall to 4.2-4.8 TB/s at others; 128 KiB is level from 2 to 8 workgroups a CU).
+template <int P>
+__global__ void __launch_bounds__(kBlock)
+k_update_big(const double2 *__restrict__ V, int64_t ldv2, int l0, int l1, double2 *__restrict__ w,
+             int64_t n2, const double *__restrict__ h, double *__restrict__ partials) {
+    __shared__ double red[kWavesPerBlock];
+    const int nl = l1 - l0;
+    const int64_t tiles = (n2 + kTileV2 - 1) / kTileV2;
+    constexpr int G = P / kEPT2;  // tiles of kTileV2 in a group
+    const int64_t groups = tiles / G;
+    double acc = 0.0;
+    for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const int64_t base = g * (int64_t)(G * kTileV2) + threadIdx.x;
+        double2 wt[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
+        for (int l = 0; l < nl; ++l, vl += ldv2) {
+            const double c = h[l];
+#pragma unroll
+            for (int u = 0; u < P; ++u) {
+                const double2 q = ld_stream(vl + u * kBlock);
+                wt[u].x -= q.x * c;
+                wt[u].y -= q.y * c;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            st_stream(w + base + u * kBlock, wt[u]);
+            acc += wt[u].x * wt[u].x + wt[u].y * wt[u].y;
+        }
+    }
+    for (int64_t t = groups * G + blockIdx.x; t < tiles; t += gridDim.x) {
+        const int64_t base = t * kTileV2 + threadIdx.x;
+        double2 wt[kEPT2];
+#pragma unroll
+        for (int u = 0; u < kEPT2; ++u) wt[u] = w[base + u * kBlock];
+        const double2 *vl = V + (int64_t)l0 * ldv2 + base;
         for (int l = 0; l < nl; ++l, vl += ldv2) {
             const double c = h[l];
 #pragma unroll

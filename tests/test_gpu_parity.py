@@ -693,6 +693,26 @@ def test_checkpoint_resume_is_bitwise(gpu, tmp_path, reorth):
             e.checkpoint_load(path)
 
 
+@pytest.mark.parametrize("reorth", ["full", "full2", "cuda_compat"])
+def test_basis_kernels_on_groups_of_tiles_match_those_on_single_tiles(gpu, monkeypatch, reorth):
+    """On long vectors k_dots and k_update take 128 KiB of every basis vector per workgroup at a time (the default from
+    2^23 rows; forced here) and the tiles that do not fill a group one by one: the same iteration as on single tiles to
+    rounding, and the CPU restatement's."""
+    for a in (la.synth_laplacian(3, 30), la.synth_laplacian(1, 100000), la.synth_laplacian(2, 181)):
+        v0 = la.gaussian_fill(17, 0, a.dimension)
+        out = {}
+        for big in ("0", "1"):
+            monkeypatch.setenv("LANCZOS_HIP_UPDATE_BIG", big)
+            monkeypatch.setenv("LANCZOS_HIP_DOTS_BIG", big)
+            with la.Engine(a, 81, reorth=reorth) as e:
+                e.set_start(v0)
+                out[big] = e.run(80)
+        assert rel_err(out["1"][0], out["0"][0]) < 1e-12 and rel_err(out["1"][1], out["0"][1]) < 1e-12
+        o = oracle.lanczos_crs(a.row_head_indexes, a.column_index, a.values, v0, 4, 81, 0.0,
+                               reorth="full" if reorth == "full2" else reorth)
+        assert rel_err(la.ritz_values(*out["1"], 80, 4), o.ritz_hist[79]) < 1e-10
+
+
 def test_iteration_as_two_plane_walks_matches_product_then_recurrence(gpu, monkeypatch):
     """Without reorthogonalisation a grid's dictionary form steps as two plane walks from 128^3 (the first leaves
     u . A u and writes nothing, the second forms A u again and applies the deferred-normalisation recurrence in its
