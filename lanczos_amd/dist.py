@@ -706,9 +706,10 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
         p2 = r2.engine.e.profile()
         if rank == 0:
             b = algorithmic_bytes(n, nnz)
-            # bytes moved: the SpMV in the matrix format in use on rank 0's slab (CRS or row-pattern dictionary)
-            # plus the 32 n of the deferred-normalisation recurrence, times the ranks
-            fmt_iter = (p2["spmv"]["bytes"] / steps2 + 32.0 * (bounds[1] - bounds[0])) * world
+            # bytes moved: what the product's and the recurrence's launches on rank 0's slab were charged (the SpMV in
+            # the matrix format in use plus the 32 n of the deferred-normalisation recurrence; 10 n + 26 n when the
+            # slab steps as two plane walks), times the ranks
+            fmt_iter = (p2["spmv"]["bytes"] + p2["recur"]["bytes"]) / steps2 * world
             out["spmv_vector_step"] = {
                 "iters_per_s": steps2 / dt2,
                 "ms_per_iter": dt2 / steps2 * 1e3,
@@ -747,8 +748,8 @@ def bench_distributed(args, workloads, algorithmic_bytes, hbm_peak, keeper=None)
                 "iters_per_s": steps2 / dt4,
                 "ms_per_iter": dt4 / steps2 * 1e3,
                 "spmv_kernel": r4.engine.e.spmv_name,
-                "bytes_moved_per_iter": (p4["spmv"]["bytes"] / steps2 + 32.0 * (bb[1] - bb[0])) * world,
-                "frac_of_hbm_peak": (p4["spmv"]["bytes"] / steps2 + 32.0 * (bb[1] - bb[0])) * steps2 / dt4 / 1e9 / hbm_peak,
+                "bytes_moved_per_iter": (p4["spmv"]["bytes"] + p4["recur"]["bytes"]) / steps2 * world,
+                "frac_of_hbm_peak": (p4["spmv"]["bytes"] + p4["recur"]["bytes"]) / dt4 / 1e9 / hbm_peak,
                 "crs_charged_bytes_per_iter": b["iter_charged"],
                 "crs_charged_bytes_over_time_GBps": b["iter_charged"] * steps2 / dt4 / 1e9,
                 "spmv_avg_ms_rank0": p4["spmv"]["ms"] / steps2,
