@@ -30,6 +30,7 @@ def lap(d, N):
     return np.concatenate(rows), np.concatenate(cols), np.concatenate(vals)
 write("lap2d.txt", *lap(2, 60))
 write("lap3d.txt", *lap(3, 20))
+write("lap3d64.txt", *lap(3, 64))   # large enough for the plane-walking dictionary form
 rng = np.random.default_rng(3)
 n = 6000
 r = rng.integers(0, n, 8 * n); c = rng.integers(0, n, 8 * n); v = rng.standard_normal(8 * n)
@@ -72,6 +73,11 @@ run one_slab_rccl   LANCZOS_HIP_QUIET=1 LANCZOS_HIP_MULTI_FORCE=1 $bin lap3d.txt
 run checkpoint      LANCZOS_HIP_QUIET=1 LANCZOS_HIP_CHECKPOINT=$out/ck.bin LANCZOS_HIP_CHECKPOINT_EVERY=10 $bin lap2d.txt crs_hip 3 35
 run resume          LANCZOS_HIP_QUIET=1 LANCZOS_HIP_RESUME=$out/ck.bin $bin lap2d.txt crs_hip 3 60
 run json_vectors    LANCZOS_HIP_JSON=1 $bin lap2d.txt crs_hip 3 30
+# forms that only large matrices take by default, forced on a 64^3 grid: the iteration as two plane walks (one GPU, two
+# slabs), the reorthogonalisation kernels on groups of tiles
+run walks           LANCZOS_HIP_QUIET=1 LANCZOS_HIP_REORTH=none LANCZOS_HIP_TWO_PASS=1 $bin lap3d64.txt crs_hip 4 40
+run walks_slabs2    LANCZOS_HIP_QUIET=1 LANCZOS_HIP_REORTH=none LANCZOS_HIP_TWO_PASS=1 LANCZOS_HIP_NGPU=2 LANCZOS_HIP_MULTI_LOOPBACK=1 $bin lap3d64.txt crs_hip 4 40
+run tile_groups     LANCZOS_HIP_QUIET=1 LANCZOS_HIP_UPDATE_BIG=1 LANCZOS_HIP_DOTS_BIG=1 $bin lap3d64.txt crs_hip 4 60
 cd $root
 if grep -q "AddressSanitizer" $out/log.txt; then echo "sanitizer reports:"; grep -c "ERROR: AddressSanitizer" $out/log.txt; fi
 grep "rc=" $out/log.txt | sort | uniq -c
