@@ -91,3 +91,4 @@ tail -40 $out/api_check.txt
 timeout -k 10 300 env LANCZOS_HIP_SPMM_HUB=2 $root/lanczos_amd/bin/api_check_asan $out > $out/api_check_hub.txt 2>&1
 echo "   api_check (hub stream forced) rc=$?" | tee -a $out/log.txt
 grep "block variant\|ok$\|failed" $out/api_check_hub.txt
+rm -f $out/lap3d64.txt   # 37 MB of triplets nobody needs afterwards
