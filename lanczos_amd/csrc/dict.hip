@@ -425,19 +425,22 @@ k_spmv_dict_ahead(int64_t n, int64_t n_ext, const uint16_t *__restrict__ pattern
 // for the three positions of the ring are built once per workgroup; the step is instantiated per position.
 constexpr int kPlanesBlock = 512;
 
-// Sum of parts[0 .. count) over the workgroup, the same in every thread and on every run.
+// Sum of parts[0 .. count) over the workgroup, the same in every thread, in the order in which the recurrence and
+// closing kernels add such partial sums up (kernels.hip.h: sum_partials over 256 threads -- a thread's entries 256
+// apart, a butterfly over the wavefront, the four wavefronts' sums in pairs): beta_{k-1} as this walk derives it and
+// as k_lazy_flush records it at the end of a run are then the same bits, and a run continues bit for bit across
+// its parts.
 template <int BLOCK>
 __device__ __forceinline__ double planes_sum_partials(const double *__restrict__ parts, int count, double *red) {
     double s = 0.0;
-    for (int i = threadIdx.x; i < count; i += BLOCK) s += parts[i];
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+    if (threadIdx.x < 256)
+        for (int i = threadIdx.x; i < count; i += 256) s += parts[i];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    double t = 0.0;
-#pragma unroll
-    for (int w = 0; w < BLOCK / 64; ++w) t += red[w];
-    return t;
+    return (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 static size_t dict_planes_lds_bytes(int halo, int patterns, int stride, int span = kDictSpan) {

@@ -187,7 +187,9 @@ struct Engine {
     void free_dict();
     int launch_spmv_dict(const double *x, const double *xdot, double *y, int *nparts, int64_t dot_lo = 0, int64_t dot_hi = -1,
                          int mode = 0, const void *recur = nullptr, double *parts_out = nullptr);
-    int enqueue_two_pass();          // an iteration without reorthogonalisation as two plane walks (dict.hip)
+    int launch_walk1(int kk);        // an iteration with deferred normalisation as two plane walks (dict.hip)
+    int launch_walk2();
+    bool spec_walk = false;          // the product launched ahead was a first walk (writes nothing)
     bool two_pass_ok();
     bool walk_pending = false;       // a row slab's iteration in progress runs as two plane walks
     int build_panels(int bits);
@@ -239,7 +241,7 @@ struct Engine {
     int combine(int m, int count, const double *coef_host, double *out_dev, int64_t out_ld);
     int restart(int p, const double *coef_host, double last_coupling);
     int selective_tail();
-    int selective_lazy_tail();
+    int selective_lazy_tail(bool walks);
     int run(int steps, double *alpha_out, double *beta_out);
     int spmv_host(const double *x_host, double *y_host);
     int spmv_noalloc(const double *x_dev, double *y_dev, double *dot_dev);

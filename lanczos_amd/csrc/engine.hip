@@ -1160,8 +1160,11 @@ int Engine::launch_product(int kk) {
 // the choice (read per iteration: tests compare the two).
 bool Engine::two_pass_ok() {
     // one GPU, or a row slab stepping phase by phase (phase_spmv* takes the first walk, phase_recur_lazy the second)
-    if (!(lazy || lazy_slab) || reorth != LANCZOS_HIP_REORTH_NONE || x_ext || ext_matvec || nnz == 0 ||
-        spmv_kind != LANCZOS_HIP_SPMV_DICT || dict_form() != 2)
+    // (with the selective rule on one GPU the recurrence is the same deferred-normalisation one, and the product launched
+    // ahead while the host decides is then the first walk of the next iteration)
+    const bool mode_ok = reorth == LANCZOS_HIP_REORTH_NONE || (reorth == LANCZOS_HIP_REORTH_SELECTIVE && lazy);
+    if (!(lazy || lazy_slab) || !mode_ok || x_ext || ext_matvec || nnz == 0 || spmv_kind != LANCZOS_HIP_SPMV_DICT ||
+        dict_form() != 2)
         return false;
     const char *env = getenv("LANCZOS_HIP_TWO_PASS");
     if (env && *env) return atoi(env) != 0;
@@ -1175,21 +1178,20 @@ bool Engine::two_pass_ok() {
     return 8.0 * (double)n >= 16.0 * 1048576.0 && planes >= 100;
 }
 
-int Engine::enqueue_two_pass() {
-    {
-        ProfScope ps(this, LANCZOS_HIP_K_SPMV, 10.0 * (double)n);  // pattern numbers and x
-        if (int rc = launch_spmv_dict(vec(k), vec(k), nullptr, &alpha_count, 0, -1, 1, nullptr, nullptr)) return rc;
-    }
-    {
-        ProfScope ps(this, LANCZOS_HIP_K_RECUR, 26.0 * (double)n);  // those, u_{k-1} read, u_{k+1} written
-        const DictRecur rc{k > 0 ? vec(k - 1) : vec(k), k, d_partials, alpha_count, norm_parts(k - 1), norm_count,
-                           d_alpha,            d_beta, h_hist};
-        int blocks = 0;
-        if (int r = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &blocks, 0, -1, 2, &rc, norm_parts(k))) return r;
-        norm_count = blocks;
-    }
-    k += 1;
-    if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
+// first walk: the partial sums of u_kk . A u_kk, nothing written
+int Engine::launch_walk1(int kk) {
+    ProfScope ps(this, LANCZOS_HIP_K_SPMV, 10.0 * (double)n);  // pattern numbers and x
+    return launch_spmv_dict(vec(kk), vec(kk), nullptr, &alpha_count, 0, -1, 1, nullptr, nullptr);
+}
+
+// second walk: A u_k again with the recurrence in its epilogue; leaves the partial sums of |u_{k+1}|^2
+int Engine::launch_walk2() {
+    ProfScope ps(this, LANCZOS_HIP_K_RECUR, 26.0 * (double)n);  // pattern numbers, x, u_{k-1} read, u_{k+1} written
+    const DictRecur rc{k > 0 ? vec(k - 1) : vec(k), k, d_partials, alpha_count, norm_parts(k - 1), norm_count,
+                       d_alpha,            d_beta, h_hist};
+    int blocks = 0;
+    if (int r = launch_spmv_dict(vec(k), vec(k), vec(k + 1), &blocks, 0, -1, 2, &rc, norm_parts(k))) return r;
+    norm_count = blocks;
     return 0;
 }
 
@@ -1197,23 +1199,26 @@ int Engine::enqueue_two_pass() {
 // into the consuming kernels, so no finaliser runs and nothing waits for the host.
 int Engine::enqueue_iteration() {
     if (int rc = check_can_step()) return rc;
-    if (!slab && two_pass_ok()) return enqueue_two_pass();
-    if (spec_spmv_k != k)  // else: launched ahead by the previous iteration, on the vector that stood
-        if (int rc = launch_product(k)) return rc;
+    const bool walks = !slab && two_pass_ok();
+    // unless launched ahead by the previous iteration, on the vector that stood and in the form this iteration takes
+    if (spec_spmv_k != k || spec_walk != walks)
+        if (int rc = walks ? launch_walk1(k) : launch_product(k)) return rc;
     spec_spmv_k = -1;
     if (lazy) {
-        const int blocks = recur_blocks();
-        {
+        if (walks) {
+            if (int rc = launch_walk2()) return rc;
+        } else {
+            const int blocks = recur_blocks();
             ProfScope ps(this, LANCZOS_HIP_K_RECUR, 32.0 * (double)n);
             hipLaunchKernelGGL(recur_lazy_kernel(), dim3(blocks), dim3(kBlock), 0, stream, (double2 *)vec(k + 1),
                                (const double2 *)vec(k), (const double2 *)(k > 0 ? vec(k - 1) : nullptr), npad / 2, k,
                                (const double *)d_partials, alpha_count, (const double *)norm_parts(k - 1), norm_count,
                                norm_parts(k), d_alpha, d_beta, h_hist);
+            norm_count = blocks;
         }
-        norm_count = blocks;
         HIP_TRY(hipGetLastError());
         if (reorth == LANCZOS_HIP_REORTH_SELECTIVE)
-            if (int rc = selective_lazy_tail()) return rc;
+            if (int rc = selective_lazy_tail(walks)) return rc;
         k += 1;
         if (h_hist) return flush_lazy();  // a host loop is reading beta_k as soon as the iteration is done
         return 0;
@@ -1289,7 +1294,7 @@ int Engine::selective_tail() {
 // The same decision on one GPU, where the basis is kept unnormalised (u_j = beta_{j-1} v_j, no
 // scaling pass).  While the host waits for ||w|| the next product is already running on the vector
 // as it stands; in the few steps that do reorthogonalise, that product is taken again.
-int Engine::selective_lazy_tail() {
+int Engine::selective_lazy_tail(bool walks) {
     {
         ProfScope ps(this, LANCZOS_HIP_K_SMALL, 8.0 * norm_count);
         hipLaunchKernelGGL(k_norm_host, dim3(1), dim3(kBlock), 0, stream, (const double *)norm_parts(k), norm_count,
@@ -1298,8 +1303,9 @@ int Engine::selective_lazy_tail() {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sel_event, stream));
     if (!ext_matvec && k + 2 < nvec && k + 1 < hist_cap && k + 1 < max_iter - 1) {
-        if (int rc = launch_spmv(vec(k + 1), vec(k + 1), vec(k + 2), &alpha_count)) return rc;
+        if (int rc = walks ? launch_walk1(k + 1) : launch_spmv(vec(k + 1), vec(k + 1), vec(k + 2), &alpha_count)) return rc;
         spec_spmv_k = k + 1;
+        spec_walk = walks;
     }
     HIP_TRY(hipEventSynchronize(sel_event));
     if (k > 0) lanczos_hip_omega_set_beta(omega, k - 1, h_hist[2 * (size_t)(k - 1) + 1]);

@@ -619,6 +619,39 @@ def test_selective_reorthogonalisation(gpu, tmp_path):
         assert rel_err(la.ritz_values(alpha, beta, k, 4), full.ritz_hist[k - 1]) < 1e-10
 
 
+def test_selective_rule_with_the_recurrence_as_two_plane_walks(gpu, monkeypatch, tmp_path):
+    """The selective rule on one GPU keeps the basis unnormalised like the run without reorthogonalisation, so on a
+    grid's plane-walking form its iteration is the same two walks (the product launched ahead while the host decides
+    is then the next iteration's first walk).  A run long enough to reorthogonalise several times: the same decisions
+    and sequences as with product + recurrence kernel, interrupted and resumed bit for bit."""
+    a = la.synth_laplacian(3, 64)
+    v0 = la.gaussian_fill(1, 0, a.dimension)
+    steps = 600
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LANCZOS_HIP_TWO_PASS", mode)
+        with la.Engine(a, steps + 1, reorth="selective") as e:
+            assert e.spmv_name.endswith("p")
+            e.set_start(v0)
+            alpha, beta = e.run(steps)
+            out[mode] = (alpha, beta, e.reorth_steps)
+    assert out["1"][2] == out["0"][2] and out["1"][2] >= 3
+    assert rel_err(out["1"][0][:200], out["0"][0][:200]) < 1e-11 and rel_err(out["1"][1][:200], out["0"][1][:200]) < 1e-11
+    for k in (100, 300):
+        assert rel_err(la.ritz_values(*out["1"][:2], k, 4), la.ritz_values(*out["0"][:2], k, 4)) < 1e-10
+    assert rel_err(la.ritz_values(*out["1"][:2], steps, 2), la.ritz_values(*out["0"][:2], steps, 2)) < 1e-9
+    path = str(tmp_path / "selw.bin")
+    with la.Engine(a, steps + 1, reorth="selective") as e:
+        e.set_start(v0)
+        a1, b1 = e.run(430)
+        e.checkpoint_save(path)
+    with la.Engine(a, steps + 1, reorth="selective") as e:
+        e.checkpoint_load(path)
+        a2, b2 = e.run(steps - 430)
+    assert np.concatenate([a1, a2]).tobytes() == out["1"][0].tobytes()
+    assert np.concatenate([b1, b2]).tobytes() == out["1"][1].tobytes()
+
+
 def test_thick_restart_converges_with_a_small_basis(gpu):
     """40 basis vectors, restarted: the lowest values of a 60 x 60 grid Laplacian to the closed form and
     to what an unrestarted run with full reorthogonalisation (src/lanczos.c:156-167) converges to."""
